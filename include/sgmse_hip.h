@@ -1,0 +1,135 @@
+/* sgmse_hip.h — C ABI of libsgmse_hip.so, the MI355X (gfx950) implementation of the reverse-SDE enhancement
+ * sampler of sp-uhh/sgmse.
+ *
+ * The reference has no C ABI of its own; its native boundary is one pybind11 function
+ * (sgmse/backbones/ncsnpp_utils/op/upfirdn2d.cpp:12-23) and everything else on the hot path is torch calls from
+ * Python.  Each entry point below names the reference interface it replaces (paths relative to the upstream tree).
+ *
+ * Conventions
+ *   - all pointers are caller-owned DEVICE pointers unless the parameter comment says "host";
+ *   - complex tensors are interleaved (re, im) fp32 pairs == torch.complex64 storage;
+ *   - tensors are dense and contiguous in the index order written in the comment;
+ *   - work is enqueued on the context's stream (the caller's current HIP stream); only the functions marked
+ *     "synchronises" wait for it;
+ *   - return 0 on success, a negative sgmse_status otherwise; sgmse_last_error(ctx) gives the message.  The Python
+ *     host layer re-raises SGMSE_EINVAL as ValueError and the rest as RuntimeError (reference: TORCH_CHECK ->
+ *     RuntimeError, upfirdn2d.cpp:8-16; registry ValueError, util/registry.py:30).
+ *   - a context is not re-entrant; use one per (device, stream).
+ */
+#ifndef SGMSE_HIP_H
+#define SGMSE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sgmse_ctx sgmse_ctx;
+
+typedef enum { SGMSE_OK = 0, SGMSE_EINVAL = -1, SGMSE_ERUNTIME = -2, SGMSE_ENOTREADY = -3 } sgmse_status;
+
+/* Constructor arguments of NCSNpp that change the graph (sgmse/backbones/ncsnpp.py:50-72,
+ * ncsnpp_48k.py:50-72).  Fixed by this implementation, as in every shipped checkpoint: resblock_type='biggan',
+ * fir=True, fir_kernel=[1,3,3,1], skip_rescale=True, resamp_with_conv=True (unused with biggan blocks),
+ * combine_method='sum', embedding_type='fourier', conditional=True, centered=True, nonlinearity='swish',
+ * init_scale=0, dropout=0. */
+typedef struct {
+  int variant;            /* 0: "ncsnpp" (ncsnpp.py), 1: "ncsnpp_48k" (ncsnpp_48k.py: output_layer before /t) */
+  int nf;                 /* base width (128) */
+  int n_levels;           /* len(ch_mult) (7) */
+  int ch_mult[8];         /* (1,1,2,2,2,2,2) */
+  int num_res_blocks;     /* 2 */
+  int n_attn;             /* len(attn_resolutions) */
+  int attn_res[8];        /* (16,) ; () for ncsnpp_48k */
+  int image_size;         /* 256 */
+  int progressive;        /* 0 'none', 1 'output_skip' */
+  int progressive_input;  /* 0 'none', 1 'input_skip' */
+  int scale_by_sigma;     /* 1 */
+} sgmse_net_cfg;
+
+/* One call of get_pc_sampler(...)() (sgmse/sampling/__init__.py:26-70).  The per-step scalars are HOST arrays of
+ * length N computed by the caller with the reference's own fp32 expressions (sgmse/sdes.py:188-219,
+ * sampling/__init__.py:56-62, correctors.py:77-79): t = linspace(T, eps, N); dt[i] = t[i]-t[i+1], dt[N-1] = t[N-1];
+ * ald_eps = 2 (snr std(t))^2; ald_noise = sqrt(2 ald_eps); G = g(t) sqrt(dt); G2 = G^2. */
+typedef struct {
+  int N;
+  int corrector;          /* 0 'none' (correctors.py:85-94), 1 'ald' (correctors.py:60-81) */
+  int corrector_steps;
+  int predictor;          /* 0 'none', 1 'reverse_diffusion' (predictors.py:56-65) */
+  int probability_flow;   /* 1: fixed-step PF-ODE Euler step (sdes.py:130-135 with probability_flow=True), no noise */
+  int denoise;            /* 1: return x_mean of the last step (sampling/__init__.py:66) */
+  float theta;            /* OUVESDE.theta */
+  float std1;             /* OUVESDE._std(T=1) for prior_sampling (sdes.py:224-229) */
+  const float* t; const float* dt; const float* ald_eps; const float* ald_noise; const float* G; const float* G2;
+  int use_graph;          /* 1: capture one predictor-corrector step as a hipGraph and replay it N times */
+} sgmse_sampler_cfg;
+
+/* -- context ------------------------------------------------------------------------------------------------ */
+int sgmse_ctx_create(int device, void* hip_stream, sgmse_ctx** out);
+void sgmse_ctx_destroy(sgmse_ctx* ctx);
+int sgmse_set_stream(sgmse_ctx* ctx, void* hip_stream);
+int sgmse_sync(sgmse_ctx* ctx);                      /* synchronises */
+const char* sgmse_last_error(sgmse_ctx* ctx);
+const char* sgmse_backend(void);                     /* "hip-gfx950" for the product library */
+
+/* -- model: replaces BackboneRegistry.get_by_name(name)(**kwargs) + load_state_dict (model.py:60-61,100-106) -- */
+int sgmse_configure(sgmse_ctx* ctx, const sgmse_net_cfg* cfg);
+/* names = the reference state_dict keys of the backbone ("output_layer.weight", "all_modules.3.weight", ...;
+ * ncsnpp.py:105,253), fp32, shapes as in the reference; every key of the configured network must be present.
+ * ptrs are host pointers (on_device = 0; synchronises) or device pointers (on_device = 1, e.g. the buffer an RCCL
+ * broadcast just filled). */
+int sgmse_load_weights(sgmse_ctx* ctx, const char* const* names, const void* const* ptrs, const long long* numels,
+                       int n, int on_device);
+int sgmse_param_count(sgmse_ctx* ctx, long long* out);
+
+/* -- NCSNpp.forward(x, time_cond) (ncsnpp.py:256-419; ncsnpp_48k.py:260-424) ---------------------------------
+ * xy: complex64 [B][2][F][T] (channel 0 = x_t, 1 = y); t: fp32 [B]; out: complex64 [B][1][F][T]. */
+int sgmse_ncsnpp_forward(sgmse_ctx* ctx, const void* xy, const float* t, void* out, int B, int F, int T);
+
+/* -- get_pc_sampler(...)() (sampling/__init__.py:52-68) with score_fn = ScoreModel.forward (model.py:307-310) --
+ * Y, out: complex64 [B][1][F][T].  noise: complex64 [1 + N*draws_per_step][B][1][F][T] standard-normal draws in the
+ * reference's call order (prior, then per step: corrector draws, predictor draw), or NULL for the in-kernel Philox
+ * stream seeded by `seed`.  *nfe receives N*(corrector_steps+1). */
+int sgmse_pc_sample(sgmse_ctx* ctx, const void* Y, void* out, int B, int F, int T, const sgmse_sampler_cfg* cfg,
+                    const void* noise, unsigned long long seed, int* nfe);
+
+/* -- SpecsDataModule.stft / istft / spec_fwd / spec_back (data_module.py:162-188,212-218) ---------------------
+ * sig fp32 [B][L] -> spec complex64 [B][n_fft/2+1][L/hop+1] (center=True, reflect pad, window fp32 [n_fft]). */
+int sgmse_stft(sgmse_ctx* ctx, const float* sig, const float* window, void* spec, int B, int L, int n_fft, int hop);
+int sgmse_istft(sgmse_ctx* ctx, const void* spec, const float* window, float* out, int B, int K, int n_fft, int hop,
+                int length);
+/* transform_type: 0 'exponent', 1 'log', 2 'none'; n = number of complex elements; in may equal out */
+int sgmse_spec_fwd(sgmse_ctx* ctx, const void* in, void* out, long long n, int transform_type, float factor, float exponent);
+int sgmse_spec_back(sgmse_ctx* ctx, const void* in, void* out, long long n, int transform_type, float factor, float exponent);
+
+/* -- upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+ *    (op/upfirdn2d.cpp:12-23, op/upfirdn2d_kernel.cu:209-369).  input fp32 [BC][H][W], kernel fp32 [kh][kw],
+ *    out fp32 [BC][(H*up_y+pad_y0+pad_y1-kh)/down_y+1][(W*up_x+pad_x0+pad_x1-kw)/down_x+1]. */
+int sgmse_upfirdn2d(sgmse_ctx* ctx, const float* input, const float* kernel, float* out, int BC, int H, int W, int kh,
+                    int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1);
+
+/* -- single layers, exported for per-op parity tests (all NCHW fp32) --------------------------------------------
+ * conv2d: F.conv2d(cat[x, x2], w, bias, padding=ks/2) (layers.py:100-124), optionally with a fused per-(b,c)
+ * affine(+SiLU) on the input, a fused residual and output scale: out = (conv + bias + res) * out_scale.
+ * x holds Cin-C2 channels, x2 (may be NULL) the remaining C2.  force_direct = 1 selects the VALU kernel. */
+int sgmse_op_conv2d(sgmse_ctx* ctx, const float* x, const float* w_oihw, const float* bias, const float* res, float* out,
+                    int B, int Cin, int Cout, int H, int W, int ks, float out_scale, int force_direct,
+                    const float* in_scale, const float* in_shift, int in_act, const float* x2, int C2);
+/* act(GroupNorm(min(C/4,32), C, eps=1e-6)(cat[x, x2])) (layerspp.py:219,243); act: 0 none, 1 SiLU.  synchronises */
+int sgmse_op_groupnorm(sgmse_ctx* ctx, const float* x, const float* gamma, const float* beta, float* out, int B, int C,
+                       int H, int W, int act, const float* x2, int C2);
+/* upsample_2d / downsample_2d with k=(1,3,3,1), factor 2 (up_or_down_sampling.py:195-257); x fp32 [BC][H][W] */
+int sgmse_op_fir(sgmse_ctx* ctx, const float* x, float* out, int BC, int H, int W, int up);
+/* attention core of AttnBlockpp (layerspp.py:82-88): qkv fp32 [B][3C][S] -> out fp32 [B][C][S] */
+int sgmse_op_attention(sgmse_ctx* ctx, const float* qkv, float* out, int B, int C, int S);
+
+/* -- measurement: one eager forward with HIP events around every kernel class.  ms and flops are host arrays of
+ *    SGMSE_NCLASS entries: conv3x3-mfma, conv1x1-mfma, conv-direct, groupnorm, fir, attention, misc.  synchronises */
+#define SGMSE_NCLASS 7
+int sgmse_profile_forward(sgmse_ctx* ctx, const void* xy, const float* t, void* out, int B, int F, int T, float* ms,
+                          double* flops);
+int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGMSE_HIP_H */

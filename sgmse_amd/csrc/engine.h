@@ -1,0 +1,932 @@
+// Host-side engine: weight store (reference state_dict names), activation arena, the NCSN++ forward as a static
+// kernel sequence, and the predictor-corrector / probability-flow sampler loop (hipGraph-captured per step).
+//
+// Mirrors, by behaviour, reference sgmse/backbones/ncsnpp.py:50-253 (module list) and :256-419 (forward),
+// ncsnpp_48k.py (ordering deltas), layerspp.py:62-91,212-274 (AttnBlockpp, ResnetBlockBigGANpp),
+// sampling/__init__.py:52-68 (pc_sampler) with predictors.py:56-65 and correctors.py:60-81, and sdes.py:72-89,
+// 130-135,188-229 (OUVE discretisation).  Nothing here is numerics except index bookkeeping: all arithmetic is in
+// the kernels.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <stdexcept>
+
+#include <sgmse_devrt.h>
+#include "kernels_conv.h"
+#include "kernels_norm_fir.h"
+#include "kernels_attn_misc.h"
+#include "kernels_stft.h"
+
+namespace sgmse {
+
+struct EngineError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define SG_CHECK(expr) do { int _e = (expr); if (_e != 0) { char _b[256]; snprintf(_b, sizeof _b, "%s failed: %s (%d)", #expr, drt::error_string(_e), _e); throw EngineError(_b); } } while (0)
+#define SG_REQUIRE(cond, msg) do { if (!(cond)) throw EngineError(std::string(msg)); } while (0)
+
+struct NetCfg {
+  int variant = 0;            // 0: ncsnpp, 1: ncsnpp_48k
+  int nf = 128;
+  int n_levels = 7;
+  int ch_mult[8] = {1, 1, 2, 2, 2, 2, 2, 0};
+  int num_res_blocks = 2;
+  int n_attn = 1;
+  int attn_res[8] = {16, 0, 0, 0, 0, 0, 0, 0};
+  int image_size = 256;
+  int progressive = 1;        // 0 none, 1 output_skip
+  int progressive_input = 1;  // 0 none, 1 input_skip
+  int scale_by_sigma = 1;
+};
+
+// ---- module layout (order and names of reference all_modules, ncsnpp.py:107-253) ---------------------------
+struct Mod {
+  enum Kind { FOURIER, LINEAR, CONV3, RES, ATTN, COMBINE, GN } kind;
+  int idx, cin, cout;
+  bool up, down;
+};
+
+inline bool cfg_has_attn(const NetCfg& c, int res) {
+  for (int i = 0; i < c.n_attn; ++i) if (c.attn_res[i] == res) return true;
+  return false;
+}
+
+inline std::vector<Mod> build_layout(const NetCfg& c) {
+  std::vector<Mod> mods;
+  auto add = [&](Mod::Kind k, int cin, int cout, bool up = false, bool down = false) {
+    mods.push_back(Mod{k, (int)mods.size(), cin, cout, up, down});
+  };
+  const int nf = c.nf, L = c.n_levels, temb = 4 * nf, channels = 4;
+  add(Mod::FOURIER, 0, nf);
+  add(Mod::LINEAR, 2 * nf, temb);
+  add(Mod::LINEAR, temb, temb);
+  add(Mod::CONV3, channels, nf);
+  std::vector<int> hs_c{nf};
+  int in_ch = nf;
+  for (int l = 0; l < L; ++l) {
+    const int res = c.image_size >> l;
+    for (int r = 0; r < c.num_res_blocks; ++r) {
+      const int out_ch = nf * c.ch_mult[l];
+      add(Mod::RES, in_ch, out_ch);
+      in_ch = out_ch;
+      if (cfg_has_attn(c, res)) add(Mod::ATTN, in_ch, in_ch);
+      hs_c.push_back(in_ch);
+    }
+    if (l != L - 1) {
+      add(Mod::RES, in_ch, in_ch, false, true);
+      if (c.progressive_input == 1) add(Mod::COMBINE, channels, in_ch);
+      hs_c.push_back(in_ch);
+    }
+  }
+  in_ch = hs_c.back();
+  add(Mod::RES, in_ch, in_ch);
+  add(Mod::ATTN, in_ch, in_ch);
+  add(Mod::RES, in_ch, in_ch);
+  for (int l = L - 1; l >= 0; --l) {
+    const int res = c.image_size >> l;
+    for (int r = 0; r < c.num_res_blocks + 1; ++r) {
+      const int out_ch = nf * c.ch_mult[l];
+      const int cin = in_ch + hs_c.back();
+      hs_c.pop_back();
+      add(Mod::RES, cin, out_ch);
+      in_ch = out_ch;
+    }
+    if (cfg_has_attn(c, res)) add(Mod::ATTN, in_ch, in_ch);
+    if (c.progressive == 1) { add(Mod::GN, in_ch, in_ch); add(Mod::CONV3, in_ch, channels); }
+    if (l != 0) add(Mod::RES, in_ch, in_ch, true, false);
+  }
+  SG_REQUIRE(hs_c.empty(), "layout: skip stack not empty");
+  if (c.progressive != 1) { add(Mod::GN, in_ch, in_ch); add(Mod::CONV3, in_ch, channels); }
+  return mods;
+}
+
+// expected parameter names and element counts, in named_parameters() order
+inline std::vector<std::pair<std::string, size_t>> param_manifest(const NetCfg& c) {
+  std::vector<std::pair<std::string, size_t>> out;
+  out.push_back({"output_layer.weight", 8});
+  out.push_back({"output_layer.bias", 2});
+  const int temb = 4 * c.nf;
+  for (const Mod& m : build_layout(c)) {
+    const std::string p = "all_modules." + std::to_string(m.idx) + ".";
+    auto put = [&](const char* k, size_t n) { out.push_back({p + k, n}); };
+    switch (m.kind) {
+      case Mod::FOURIER: put("W", c.nf); break;
+      case Mod::LINEAR: put("weight", (size_t)m.cout * m.cin); put("bias", m.cout); break;
+      case Mod::CONV3: put("weight", (size_t)m.cout * m.cin * 9); put("bias", m.cout); break;
+      case Mod::GN: put("weight", m.cin); put("bias", m.cin); break;
+      case Mod::COMBINE: put("Conv_0.weight", (size_t)m.cout * m.cin); put("Conv_0.bias", m.cout); break;
+      case Mod::ATTN:
+        put("GroupNorm_0.weight", m.cin); put("GroupNorm_0.bias", m.cin);
+        for (int i = 0; i < 4; ++i) {
+          out.push_back({p + "NIN_" + std::to_string(i) + ".W", (size_t)m.cin * m.cin});
+          out.push_back({p + "NIN_" + std::to_string(i) + ".b", (size_t)m.cin});
+        }
+        break;
+      case Mod::RES:
+        put("GroupNorm_0.weight", m.cin); put("GroupNorm_0.bias", m.cin);
+        put("Conv_0.weight", (size_t)m.cout * m.cin * 9); put("Conv_0.bias", m.cout);
+        put("Dense_0.weight", (size_t)m.cout * temb); put("Dense_0.bias", m.cout);
+        put("GroupNorm_1.weight", m.cout); put("GroupNorm_1.bias", m.cout);
+        put("Conv_1.weight", (size_t)m.cout * m.cout * 9); put("Conv_1.bias", m.cout);
+        if (m.cin != m.cout || m.up || m.down) { put("Conv_2.weight", (size_t)m.cout * m.cin); put("Conv_2.bias", m.cout); }
+        break;
+    }
+  }
+  return out;
+}
+
+// ---- weight packing on the device --------------------------------------------------------------------------
+// dst[blk][c][tap][j] = W(co = blk*co_t + j, c, tap); the logical weight is the channel-concatenation of up to three
+// sources, each either OIHW [cout_s][cin][taps] (io = 0) or NIN's [cin][cout_s] (io = 1, taps = 1).
+struct PackArgs { const float* src[3]; int nsrc, cout_per_src, io, cin, taps, cout, co_t; float* dst; size_t total; };
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs p) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= p.total) return;
+  const int j = (int)(e % p.co_t);
+  size_t r = e / p.co_t;
+  const int t = (int)(r % p.taps); r /= p.taps;
+  const int c = (int)(r % p.cin);
+  const int blk = (int)(r / p.cin);
+  const int co = blk * p.co_t + j;
+  float v = 0.f;
+  if (co < p.cout) {
+    const int s = co / p.cout_per_src, cj = co % p.cout_per_src;
+    v = p.io ? p.src[s][(size_t)c * p.cout_per_src + cj] : p.src[s][((size_t)cj * p.cin + c) * p.taps + t];
+  }
+  p.dst[e] = v;
+}
+
+// [cin][cout] -> [cout][cin]
+__global__ __launch_bounds__(256) void transpose_io_kernel(const float* src, float* dst, int cin, int cout) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= cin * cout) return;
+  const int co = e / cin, c = e % cin;
+  dst[e] = src[(size_t)c * cout + co];
+}
+
+// ---- arena ---------------------------------------------------------------------------------------------------
+// Deterministic first-fit pool over one device allocation.  In "measure" mode nothing is backed by memory and only
+// the high-water mark is tracked (used to size the real arena before the first run / graph capture).
+class Arena {
+ public:
+  void reset() { free_.clear(); free_.push_back({0, cap_}); live_.clear(); }
+  void configure(char* base, size_t cap) { base_ = base; cap_ = cap; live_.clear(); reset(); }
+  // measure mode hands out addresses from an unmapped fake range; they are never dereferenced (dry run)
+  void measure_mode() { base_ = reinterpret_cast<char*>(uintptr_t(1) << 44); cap_ = size_t(1) << 42; high_ = 0; reset(); live_.clear(); }
+  size_t high_water() const { return high_; }
+  float* alloc(size_t nfloats) {
+    size_t bytes = (nfloats * 4 + 255) / 256 * 256;
+    if (bytes == 0) bytes = 256;
+    for (size_t i = 0; i < free_.size(); ++i) {
+      if (free_[i].second >= bytes) {
+        const size_t off = free_[i].first;
+        free_[i].first += bytes; free_[i].second -= bytes;
+        if (free_[i].second == 0) free_.erase(free_.begin() + i);
+        live_[off] = bytes;
+        if (off + bytes > high_) high_ = off + bytes;
+        return reinterpret_cast<float*>(base_ + off);
+      }
+    }
+    throw EngineError("activation arena exhausted");
+  }
+  void release(float* p) {
+    if (!p) return;
+    const size_t off = size_t(reinterpret_cast<char*>(p) - base_);
+    auto it = live_.find(off);
+    SG_REQUIRE(it != live_.end(), "arena: bad release");
+    size_t bytes = it->second;
+    live_.erase(it);
+    size_t i = 0;
+    while (i < free_.size() && free_[i].first < off) ++i;
+    free_.insert(free_.begin() + i, {off, bytes});
+    if (i + 1 < free_.size() && free_[i].first + free_[i].second == free_[i + 1].first) {
+      free_[i].second += free_[i + 1].second; free_.erase(free_.begin() + i + 1);
+    }
+    if (i > 0 && free_[i - 1].first + free_[i - 1].second == free_[i].first) {
+      free_[i - 1].second += free_[i].second; free_.erase(free_.begin() + i);
+    }
+  }
+ private:
+  char* base_ = nullptr;
+  size_t cap_ = 0, high_ = 0;
+  std::vector<std::pair<size_t, size_t>> free_;
+  std::map<size_t, size_t> live_;
+};
+
+struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; };
+
+struct ConvW {            // one convolution's parameters on the device
+  const float* oihw = nullptr;   // [cout][cin][ks][ks] (for NIN: transposed copy)
+  const float* packed = nullptr; // MFMA layout (null if the shape is not MFMA-eligible)
+  const float* bias = nullptr;
+  int ks = 1, cin = 0, cout = 0, co_t = 0;
+};
+
+struct ResW { const float *g0w, *g0b, *g1w, *g1b; ConvW c0, c1, c2; bool has_c2; int temb_off; };
+struct AttnW { const float *gw, *gb; ConvW qkv, proj; };
+
+struct SamplerCfg {
+  int N = 30;
+  int corrector = 1;        // 0 none, 1 ald
+  int corrector_steps = 1;
+  int predictor = 1;        // 0 none, 1 reverse_diffusion
+  int probability_flow = 0;
+  int denoise = 1;
+  float theta = 1.5f;
+  float std1 = 0.f;         // OUVE._std(T)
+  const float* t = nullptr; const float* dt = nullptr; const float* ald_eps = nullptr; const float* ald_noise = nullptr;
+  const float* G = nullptr; const float* G2 = nullptr;   // host arrays [N]
+  int use_graph = 1;
+};
+
+class Engine {
+ public:
+  explicit Engine(int device, void* stream) : device_(device) {
+    SG_CHECK(drt::set_device(device));
+    stream_ = reinterpret_cast<drt::stream_t>(stream);
+  }
+  ~Engine() {
+    for (void* p : owned_) drt::free_dev(p);
+    if (graph_valid_) drt::graph_destroy(&graph_);
+  }
+
+  drt::stream_t stream() const { return stream_; }
+  void set_stream(void* s) { stream_ = reinterpret_cast<drt::stream_t>(s); invalidate_graph(); }
+
+  // ---- weights ----------------------------------------------------------------------------------------------
+  void set_config(const NetCfg& c) { cfg_ = c; layout_ = build_layout(c); weights_ready_ = false; invalidate_graph(); }
+  const NetCfg& config() const { return cfg_; }
+
+  void load_weights(const char* const* names, const void* const* ptrs, const long long* numels, int n, int on_device) {
+    auto manifest = param_manifest(cfg_);
+    std::map<std::string, size_t> want;
+    size_t total = 0;
+    for (auto& kv : manifest) { want[kv.first] = kv.second; total += (kv.second + 63) / 64 * 64; }
+    float* blob = static_cast<float*>(dev_alloc(total * 4));
+    blob_ = blob; blob_elems_ = total;
+    std::map<std::string, std::pair<const void*, long long>> given;
+    for (int i = 0; i < n; ++i) given[names[i]] = {ptrs[i], numels[i]};
+    size_t off = 0;
+    W_.clear();
+    for (auto& kv : manifest) {
+      auto it = given.find(kv.first);
+      if (it == given.end()) throw EngineError("load_weights: missing parameter " + kv.first);
+      if ((size_t)it->second.second != kv.second)
+        throw EngineError("load_weights: size mismatch for " + kv.first + " (got " + std::to_string(it->second.second) +
+                          ", want " + std::to_string(kv.second) + ")");
+      if (on_device) SG_CHECK(drt::memcpy_d2d(blob + off, it->second.first, kv.second * 4, stream_));
+      else SG_CHECK(drt::memcpy_h2d(blob + off, it->second.first, kv.second * 4, stream_));
+      W_[kv.first] = blob + off;
+      off += (kv.second + 63) / 64 * 64;
+    }
+    if (!on_device) SG_CHECK(drt::stream_sync(stream_));  // host buffers may be released by the caller
+    finalize_weights();
+  }
+
+  size_t param_count() const { size_t n = 0; for (auto& kv : param_manifest(cfg_)) n += kv.second; return n; }
+
+  // ---- network forward ----------------------------------------------------------------------------------------
+  // x: complex64 [B][1][F][T] with batch stride xbs (complex elements), y likewise; t: device fp32.
+  // out: complex64 [B][1][F][T] = sign * NCSNpp(cat[x,y], t).
+  struct FwdCtl {
+    const float* bias_table; int bias_bstride, bias_sstride; const int* step_ptr;
+    const float* tvals; int t_bstride, t_sstride; float sign;
+  };
+
+  void forward_xy(const float2* xy, const float* t_dev, float2* out, int B, int F, int T) {
+    // public single-evaluation entry: xy is [B][2][F][T]; t is a device array [B]
+    require_ready();
+    ensure_shape(B, F, T, /*nrows=*/B);
+    compute_temb(t_dev, B);
+    FwdCtl ctl{bias_table_, tot_temb_, 0, nullptr, t_dev, 1, 0, 1.0f};
+    const long long FT = (long long)F * T;
+    arena_.reset();
+    run_forward(xy, 2 * FT, xy + FT, 2 * FT, out, B, F, T, ctl);
+  }
+
+  // ---- sampler --------------------------------------------------------------------------------------------------
+  void pc_sample(const float2* Y, float2* out, int B, int F, int T, const SamplerCfg& sc, const float2* noise,
+                 unsigned long long seed) {
+    require_ready();
+    SG_REQUIRE(sc.N >= 1 && sc.t && sc.dt && sc.G && sc.G2, "pc_sample: step table missing");
+    SG_REQUIRE(sc.corrector == 0 || (sc.ald_eps && sc.ald_noise), "pc_sample: ALD table missing");
+    ensure_shape(B, F, T, sc.N);
+    const size_t n = (size_t)B * F * T;
+    // step table -> device
+    std::vector<float> tab((size_t)sc.N * SC_STRIDE, 0.f), tv(sc.N);
+    for (int i = 0; i < sc.N; ++i) {
+      float* r = &tab[(size_t)i * SC_STRIDE];
+      r[SC_T] = sc.t[i]; r[SC_DT] = sc.dt[i]; r[SC_G] = sc.G[i]; r[SC_G2] = sc.G2[i];
+      if (sc.corrector) { r[SC_ALD_EPS] = sc.ald_eps[i]; r[SC_ALD_NOISE] = sc.ald_noise[i]; }
+      tv[i] = sc.t[i];
+    }
+    SG_CHECK(drt::memcpy_h2d(step_table_, tab.data(), tab.size() * 4, stream_));
+    SG_CHECK(drt::memcpy_h2d(tsteps_, tv.data(), tv.size() * 4, stream_));
+    SG_CHECK(drt::stream_sync(stream_));
+    compute_temb(tsteps_, sc.N);
+
+    const int ncorr = sc.corrector ? sc.corrector_steps : 0;
+    const bool pred_noise = sc.predictor == 1 && !sc.probability_flow;
+    const int draws_per_step = ncorr + (pred_noise ? 1 : 0);
+
+    SamplerArgs sa{};
+    sa.x = sx_; sa.x_mean = sxm_; sa.y = Y; sa.score = sscore_; sa.noise = noise; sa.seed = seed;
+    sa.table = step_table_; sa.step_ptr = step_ctr_; sa.theta = sc.theta; sa.std1 = sc.std1; sa.n = (int)n;
+    sa.score_w = sc.probability_flow ? 0.5f : 1.0f;
+    const dim3 eg((unsigned)((n + 255) / 256));
+
+    sa.draw_base = 0; sa.draw_per_step = 0;
+    DRT_LAUNCH(sampler_prior_kernel, eg, dim3(256), stream_, sa);
+    SG_CHECK(drt::memcpy_d2d(sxm_, sx_, n * 8, stream_));
+    DRT_LAUNCH(step_set_kernel, dim3(1), dim3(64), stream_, step_ctr_, 0);
+
+    FwdCtl ctl{bias_table_, 0, tot_temb_, step_ctr_, tsteps_, 0, 1, -1.0f};
+    const long long FT = (long long)F * T;
+    auto step_body = [&]() {
+      for (int cs = 0; cs < ncorr; ++cs) {
+        arena_.reset();
+        run_forward(sx_, FT, Y, FT, sscore_, B, F, T, ctl);
+        SamplerArgs a = sa; a.draw_base = 1 + cs; a.draw_per_step = draws_per_step;
+        DRT_LAUNCH(sampler_ald_kernel, eg, dim3(256), stream_, a);
+      }
+      if (sc.predictor == 1) {
+        arena_.reset();
+        run_forward(sx_, FT, Y, FT, sscore_, B, F, T, ctl);
+        SamplerArgs a = sa; a.draw_base = 1 + ncorr; a.draw_per_step = draws_per_step; a.add_noise = pred_noise ? 1 : 0;
+        DRT_LAUNCH(sampler_revdiff_kernel, eg, dim3(256), stream_, a);
+      }
+      DRT_LAUNCH(step_inc_kernel, dim3(1), dim3(64), stream_, step_ctr_);
+    };
+
+    GraphKey key{B, F, T, sc.corrector, ncorr, sc.predictor, sc.probability_flow, (const void*)Y, (const void*)noise, seed,
+                 sc.theta, draws_per_step};
+    const bool want_graph = sc.use_graph && drt::graphs_supported();
+    if (want_graph) {
+      if (!graph_valid_ || !(key == graph_key_)) {
+        invalidate_graph();
+        SG_CHECK(drt::stream_sync(stream_));
+        SG_CHECK(drt::graph_begin_capture(stream_));
+        step_body();
+        SG_CHECK(drt::graph_end_capture(stream_, &graph_));
+        graph_valid_ = true; graph_key_ = key;
+      }
+      for (int i = 0; i < sc.N; ++i) SG_CHECK(drt::graph_launch(&graph_, stream_));
+    } else {
+      for (int i = 0; i < sc.N; ++i) step_body();
+    }
+    SG_CHECK(drt::memcpy_d2d(out, sc.denoise ? sxm_ : sx_, n * 8, stream_));
+    nfe_ = sc.N * (ncorr + (sc.predictor == 1 ? 1 : 0));
+  }
+  int last_nfe() const { return nfe_; }
+  size_t arena_bytes() const { return arena_cap_; }
+
+  // ---- single ops (op-level C ABI + tests) ------------------------------------------------------------------
+  void op_conv2d(const float* x, const float* w_oihw, const float* bias, const float* res, float* out, int B, int Cin,
+                 int Cout, int H, int W, int ks, float out_scale, int force_direct, const float* in_scale,
+                 const float* in_shift, int in_act, const float* x2, int C2) {
+    ConvArgs a{};
+    a.src1 = x; a.src2 = x2; a.C1 = Cin - C2; a.C2 = C2; a.bias = bias; a.res = res; a.out_scale = out_scale; a.out = out;
+    a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
+    ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
+    if (pl.mfma && !force_direct && (C2 == 0 || a.C1 % ((ks == 3) ? 8 : 32) == 0)) {
+      const size_t ne = packed_weight_elems(ks, Cin, Cout, pl.co_t);
+      float* pk = static_cast<float*>(dev_alloc_tmp(ne * 4));
+      PackArgs pa{}; pa.src[0] = w_oihw; pa.nsrc = 1; pa.cout_per_src = Cout; pa.io = 0; pa.cin = Cin; pa.taps = ks * ks;
+      pa.cout = Cout; pa.co_t = pl.co_t; pa.dst = pk; pa.total = ne;
+      DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, pa);
+      a.w = pk;
+      launch_conv_mfma(a, ks, pl, stream_);
+      SG_CHECK(drt::stream_sync(stream_));
+      free_tmp(pk);
+    } else {
+      a.w = w_oihw;
+      launch_conv_direct(a, ks, stream_);
+    }
+    check_launch();
+  }
+
+  void op_groupnorm(const float* x, const float* gamma, const float* beta, float* out, int B, int C, int H, int W, int act,
+                    const float* x2, int C2) {
+    const int HW = H * W, C1 = C - C2;
+    float* stats = static_cast<float*>(dev_alloc_tmp((size_t)B * C * 2 * 4));
+    float* sc = static_cast<float*>(dev_alloc_tmp((size_t)B * C * 4));
+    float* sh = static_cast<float*>(dev_alloc_tmp((size_t)B * C * 4));
+    DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C), dim3(256), stream_, x, x2, C1, C2, HW, stats);
+    const int G = std::min(C / 4, 32);
+    DRT_LAUNCH(gn_finalize_kernel, dim3(B), dim3(256), stream_, (const float*)stats, gamma, beta, C, G, HW, 1e-6f, sc, sh);
+    DRT_LAUNCH(gn_apply_kernel, dim3((HW + 1023) / 1024, B * C), dim3(256), stream_, x, x2, C1, C2, HW, (const float*)sc,
+               (const float*)sh, act, out);
+    SG_CHECK(drt::stream_sync(stream_));
+    check_launch();
+    free_tmp(stats); free_tmp(sc); free_tmp(sh);
+  }
+
+  void op_fir(const float* x, float* out, int BC, int H, int W, int up) {
+    FirArgs fa{x, out, nullptr, nullptr, 0, BC, H, W};
+    if (up) DRT_LAUNCH(fir_up2_kernel, dim3((H * W + 255) / 256, BC), dim3(256), stream_, fa);
+    else DRT_LAUNCH(fir_down2_kernel, dim3(((H / 2) * (W / 2) + 255) / 256, BC), dim3(256), stream_, fa);
+    check_launch();
+  }
+
+  void op_upfirdn2d(const float* x, const float* kern, float* out, int BC, int H, int W, int kh, int kw, int up_x, int up_y,
+                    int down_x, int down_y, int px0, int px1, int py0, int py1) {
+    UpfirdnArgs a{x, kern, out, BC, H, W, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1, 0, 0};
+    a.Ho = (H * up_y + py0 + py1 - kh) / down_y + 1;
+    a.Wo = (W * up_x + px0 + px1 - kw) / down_x + 1;
+    SG_REQUIRE(a.Ho > 0 && a.Wo > 0, "upfirdn2d: empty output");
+    DRT_LAUNCH(upfirdn2d_generic_kernel, dim3((a.Ho * a.Wo + 255) / 256, BC), dim3(256), stream_, a);
+    check_launch();
+  }
+
+  void op_attention(const float* qkv, float* out, int B, int C, int S) {
+    AttnArgs a{qkv, out, B, C, S, 1.0f / sqrtf((float)C)};
+    SG_REQUIRE(launch_attn_core(a, stream_), "attention: C must be 32, 64, 128 or 256");
+    check_launch();
+  }
+
+  void op_stft(const float* sig, const float* window, float2* spec, int B, int L, int n_fft, int hop) {
+    SG_REQUIRE(n_fft <= kMaxNfft && n_fft >= 2 && hop >= 1 && L > n_fft / 2, "stft: unsupported geometry");
+    const float2* tw = twiddle(n_fft);
+    StftArgs a{sig, window, tw, spec, L, n_fft, hop, n_fft / 2 + 1, (L + 2 * (n_fft / 2) - n_fft) / hop + 1};
+    DRT_LAUNCH(stft_kernel, dim3(a.K, B), dim3(256), stream_, a);
+    check_launch();
+  }
+
+  void op_istft(const float2* spec, const float* window, float* out, int B, int K, int n_fft, int hop, int length) {
+    SG_REQUIRE(n_fft <= kMaxNfft && n_fft >= 2 && hop >= 1, "istft: unsupported geometry");
+    SG_REQUIRE(K >= 1 && length >= 1 && length + n_fft / 2 <= n_fft + hop * (K - 1), "istft: length exceeds the overlap-add span");
+    const float2* tw = twiddle(n_fft);
+    IstftArgs a{spec, window, tw, out, n_fft, hop, n_fft / 2 + 1, K, length};
+    DRT_LAUNCH(istft_kernel, dim3((length + 255) / 256, B), dim3(256), stream_, a);
+    check_launch();
+  }
+
+  void op_spec_xform(const float2* in, float2* out, size_t n, int type, float factor, float exponent, int inverse) {
+    SpecXformArgs a{in, out, n, type, factor, exponent, inverse};
+    DRT_LAUNCH(spec_xform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), stream_, a);
+    check_launch();
+  }
+
+  void sync() { SG_CHECK(drt::stream_sync(stream_)); }
+
+  // per-kernel-class timing of one forward (eager, events on this stream); fills ms per class
+  enum { TC_CONV3 = 0, TC_CONV1, TC_DIRECT, TC_GN, TC_FIR, TC_ATTN, TC_MISC, TC_COUNT };
+  void profile_forward(const float2* xy, const float* t_dev, float2* out, int B, int F, int T, float* ms_out, double* flops_out) {
+    prof_ = true;
+    for (int i = 0; i < TC_COUNT; ++i) { prof_ms_[i] = 0.f; prof_flops_[i] = 0.0; }
+    forward_xy(xy, t_dev, out, B, F, T);
+    prof_ = false;
+    for (int i = 0; i < TC_COUNT; ++i) { ms_out[i] = prof_ms_[i]; flops_out[i] = prof_flops_[i]; }
+  }
+
+ private:
+  // ---- memory helpers ------------------------------------------------------------------------------------------
+  void* dev_alloc(size_t bytes) {
+    void* p = nullptr;
+    SG_CHECK(drt::malloc_dev(&p, bytes ? bytes : 256));
+    owned_.push_back(p);
+    return p;
+  }
+  void* dev_alloc_tmp(size_t bytes) { void* p = nullptr; SG_CHECK(drt::malloc_dev(&p, bytes ? bytes : 256)); return p; }
+  void free_tmp(void* p) { drt::free_dev(p); }
+  void dev_free_owned(void* p) {
+    for (size_t i = 0; i < owned_.size(); ++i) if (owned_[i] == p) { owned_.erase(owned_.begin() + i); break; }
+    drt::free_dev(p);
+  }
+  void check_launch() { SG_CHECK(drt::last_error()); }
+  void require_ready() { SG_REQUIRE(weights_ready_, "weights not loaded (call sgmse_load_weights first)"); }
+  void invalidate_graph() { if (graph_valid_) { drt::graph_destroy(&graph_); graph_valid_ = false; } }
+
+  const float2* twiddle(int n_fft) {
+    auto it = twiddles_.find(n_fft);
+    if (it != twiddles_.end()) return it->second;
+    std::vector<float2> h(n_fft);
+    for (int m = 0; m < n_fft; ++m) {
+      const double ang = 2.0 * 3.14159265358979323846 * (double)m / (double)n_fft;
+      h[m] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    float2* d = static_cast<float2*>(dev_alloc(sizeof(float2) * n_fft));
+    SG_CHECK(drt::memcpy_h2d(d, h.data(), sizeof(float2) * n_fft, stream_));
+    SG_CHECK(drt::stream_sync(stream_));
+    twiddles_[n_fft] = d;
+    return d;
+  }
+
+  const float* Wp(const std::string& name) const {
+    auto it = W_.find(name);
+    if (it == W_.end()) throw EngineError("internal: unknown parameter " + name);
+    return it->second;
+  }
+
+  ConvW make_conv(const std::string& wname, const std::string& bname, int ks, int cin, int cout) {
+    ConvW c; c.ks = ks; c.cin = cin; c.cout = cout;
+    c.oihw = Wp(wname); c.bias = bname.empty() ? nullptr : Wp(bname);
+    ConvPlan pl = choose_conv_plan(ks, cin, cout, 8, 32);
+    if (pl.mfma) {
+      c.co_t = pl.co_t;
+      const size_t ne = packed_weight_elems(ks, cin, cout, pl.co_t);
+      float* pk = static_cast<float*>(dev_alloc(ne * 4));
+      PackArgs pa{}; pa.src[0] = c.oihw; pa.nsrc = 1; pa.cout_per_src = cout; pa.io = 0; pa.cin = cin; pa.taps = ks * ks;
+      pa.cout = cout; pa.co_t = pl.co_t; pa.dst = pk; pa.total = ne;
+      DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, pa);
+      c.packed = pk;
+    }
+    return c;
+  }
+
+  // NIN weights W[cin][cout] (layers.py:549); nsrc of them concatenated along cout (fused q|k|v projection)
+  ConvW make_nin(const std::string& pre, const int* which, int nsrc, int C) {
+    ConvW c; c.ks = 1; c.cin = C; c.cout = nsrc * C;
+    float* tr = static_cast<float*>(dev_alloc((size_t)nsrc * C * C * 4));
+    float* bb = static_cast<float*>(dev_alloc((size_t)nsrc * C * 4));
+    for (int s = 0; s < nsrc; ++s) {
+      const std::string n = pre + "NIN_" + std::to_string(which[s]);
+      DRT_LAUNCH(transpose_io_kernel, dim3((C * C + 255) / 256), dim3(256), stream_, Wp(n + ".W"), tr + (size_t)s * C * C, C, C);
+      SG_CHECK(drt::memcpy_d2d(bb + (size_t)s * C, Wp(n + ".b"), (size_t)C * 4, stream_));
+    }
+    c.oihw = tr; c.bias = bb;
+    ConvPlan pl = choose_conv_plan(1, C, c.cout, 8, 32);
+    if (pl.mfma) {
+      c.co_t = pl.co_t;
+      const size_t ne = packed_weight_elems(1, C, c.cout, pl.co_t);
+      float* pk = static_cast<float*>(dev_alloc(ne * 4));
+      PackArgs pa{}; pa.nsrc = nsrc; pa.cout_per_src = C; pa.io = 1; pa.cin = C; pa.taps = 1; pa.cout = c.cout; pa.co_t = pl.co_t;
+      pa.dst = pk; pa.total = ne;
+      for (int s = 0; s < nsrc; ++s) pa.src[s] = Wp(pre + "NIN_" + std::to_string(which[s]) + ".W");
+      DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, pa);
+      c.packed = pk;
+    }
+    return c;
+  }
+
+  void finalize_weights() {
+    res_.clear(); attn_.clear(); conv_.clear(); gn_.clear();
+    std::vector<DenseDesc> descs;
+    int off = 0;
+    for (const Mod& m : layout_) {
+      const std::string p = "all_modules." + std::to_string(m.idx) + ".";
+      if (m.kind == Mod::RES) {
+        ResW r{};
+        r.g0w = Wp(p + "GroupNorm_0.weight"); r.g0b = Wp(p + "GroupNorm_0.bias");
+        r.g1w = Wp(p + "GroupNorm_1.weight"); r.g1b = Wp(p + "GroupNorm_1.bias");
+        r.c0 = make_conv(p + "Conv_0.weight", p + "Conv_0.bias", 3, m.cin, m.cout);
+        r.c1 = make_conv(p + "Conv_1.weight", p + "Conv_1.bias", 3, m.cout, m.cout);
+        r.has_c2 = (m.cin != m.cout) || m.up || m.down;
+        if (r.has_c2) r.c2 = make_conv(p + "Conv_2.weight", p + "Conv_2.bias", 1, m.cin, m.cout);
+        r.temb_off = off;
+        descs.push_back(DenseDesc{Wp(p + "Dense_0.weight"), Wp(p + "Dense_0.bias"), r.c0.bias, m.cout, off});
+        off += m.cout;
+        res_[m.idx] = r;
+      } else if (m.kind == Mod::ATTN) {
+        AttnW a{};
+        a.gw = Wp(p + "GroupNorm_0.weight"); a.gb = Wp(p + "GroupNorm_0.bias");
+        const int qkv[3] = {0, 1, 2}, pr[1] = {3};
+        a.qkv = make_nin(p, qkv, 3, m.cin);
+        a.proj = make_nin(p, pr, 1, m.cin);
+        attn_[m.idx] = a;
+      } else if (m.kind == Mod::CONV3) {
+        conv_[m.idx] = make_conv(p + "weight", p + "bias", 3, m.cin, m.cout);
+      } else if (m.kind == Mod::COMBINE) {
+        conv_[m.idx] = make_conv(p + "Conv_0.weight", p + "Conv_0.bias", 1, m.cin, m.cout);
+      } else if (m.kind == Mod::GN) {
+        gn_[m.idx] = {Wp(p + "weight"), Wp(p + "bias")};
+      }
+    }
+    tot_temb_ = off;
+    n_dense_ = (int)descs.size();
+    dense_descs_ = static_cast<DenseDesc*>(dev_alloc(sizeof(DenseDesc) * descs.size()));
+    SG_CHECK(drt::memcpy_h2d(dense_descs_, descs.data(), sizeof(DenseDesc) * descs.size(), stream_));
+    SG_CHECK(drt::stream_sync(stream_));
+    check_launch();
+    weights_ready_ = true;
+    shape_B_ = 0;
+  }
+
+  // ---- shape-dependent buffers --------------------------------------------------------------------------------
+  void ensure_shape(int B, int F, int T, int nrows) {
+    SG_REQUIRE(B >= 1 && F >= 1 && T >= 1, "bad shape");
+    const int down = 1 << (cfg_.n_levels - 1);
+    SG_REQUIRE(F % down == 0 && T % down == 0, "F and T must be multiples of 2^(levels-1) (pad_spec pads T to a multiple of 64)");
+    if (B != shape_B_ || F != shape_F_ || T != shape_T_) {
+      invalidate_graph();
+      // size the arena by a dry run
+      arena_.measure_mode();
+      dry_ = true;
+      FwdCtl ctl{nullptr, 0, 0, nullptr, nullptr, 0, 0, 1.f};
+      run_forward(nullptr, 0, nullptr, 0, nullptr, B, F, T, ctl);
+      dry_ = false;
+      const size_t need = arena_.high_water() + (1 << 20);
+      if (need > arena_cap_) {
+        if (arena_base_) dev_free_owned(arena_base_);
+        arena_base_ = static_cast<char*>(dev_alloc(need));
+        arena_cap_ = need;
+      }
+      arena_.configure(arena_base_, arena_cap_);
+      const size_t n = (size_t)B * F * T;
+      if (n > samp_n_) {
+        for (float2** q : {&sx_, &sxm_, &sscore_}) { if (*q) dev_free_owned(*q); *q = static_cast<float2*>(dev_alloc(n * 8)); }
+        samp_n_ = n;
+      }
+      if (!step_ctr_) step_ctr_ = static_cast<int*>(dev_alloc(256));
+      shape_B_ = B; shape_F_ = F; shape_T_ = T;
+    }
+    if (nrows > temb_rows_) {
+      invalidate_graph();
+      if (temb_act_) { dev_free_owned(temb_act_); dev_free_owned(bias_table_); dev_free_owned(step_table_); dev_free_owned(tsteps_); }
+      temb_rows_ = std::max(nrows, 64);
+      temb_act_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * 4 * cfg_.nf * 4));
+      bias_table_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * std::max(tot_temb_, 1) * 4));
+      step_table_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * SC_STRIDE * 4));
+      tsteps_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * 4));
+    }
+  }
+
+  void compute_temb(const float* t_dev, int rows) {
+    TembArgs ta{t_dev, rows, Wp("all_modules.0.W"), Wp("all_modules.1.weight"), Wp("all_modules.1.bias"),
+                Wp("all_modules.2.weight"), Wp("all_modules.2.bias"), cfg_.nf, temb_act_};
+    SG_REQUIRE(cfg_.nf <= 256, "nf > 256 not supported by temb kernel");
+    DRT_LAUNCH(temb_mlp_kernel, dim3(rows), dim3(256), stream_, ta);
+    DRT_LAUNCH(temb_dense_kernel, dim3(n_dense_, rows), dim3(256), stream_, (const DenseDesc*)dense_descs_,
+               (const float*)temb_act_, 4 * cfg_.nf, bias_table_, tot_temb_);
+    check_launch();
+  }
+
+  // ---- op wrappers used by the forward ------------------------------------------------------------------------
+  struct Xform { const float* scale = nullptr; const float* shift = nullptr; int act = 0; };
+
+  void tick(int cls, double flops) {
+    if (!prof_) return;
+    drt::event_record(&ev_b_, stream_);
+    drt::event_sync(&ev_b_);
+    prof_ms_[cls] += drt::event_elapsed_ms(ev_a_, ev_b_);
+    prof_flops_[cls] += flops;
+  }
+  void tock() { if (prof_) { if (!ev_init_) { drt::event_create(&ev_a_); drt::event_create(&ev_b_); ev_init_ = true; } drt::event_record(&ev_a_, stream_); } }
+
+  Tensor new_tensor(int C, int H, int W) { Tensor t; t.C = C; t.H = H; t.W = W; t.p = arena_.alloc((size_t)B_ * C * H * W); return t; }
+  void drop(Tensor& t) { arena_.release(t.p); t.p = nullptr; }
+
+  void gn_coeffs(const Tensor& a, const Tensor* b, const float* gamma, const float* beta, float** sc, float** sh) {
+    const int C = a.C + (b ? b->C : 0), HW = a.H * a.W;
+    float* stats = arena_.alloc((size_t)B_ * C * 2);
+    *sc = arena_.alloc((size_t)B_ * C);
+    *sh = arena_.alloc((size_t)B_ * C);
+    if (!dry_) {
+      tock();
+      DRT_LAUNCH(gn_chan_stats_kernel, dim3(B_ * C), dim3(256), stream_, (const float*)a.p, (const float*)(b ? b->p : nullptr), a.C,
+                 b ? b->C : 0, HW, stats);
+      const int G = std::min(C / 4, 32);
+      DRT_LAUNCH(gn_finalize_kernel, dim3(B_), dim3(256), stream_, (const float*)stats, gamma, beta, C, G, HW, 1e-6f, *sc, *sh);
+      tick(TC_GN, 0.0);
+    }
+    arena_.release(stats);
+  }
+
+  Tensor conv(const ConvW& w, const Tensor& a, const Tensor* b, const Xform& xf, const float* bias, const float* bias2,
+              const float* res, float out_scale, const FwdCtl& ctl) {
+    const int Cin = a.C + (b ? b->C : 0);
+    SG_REQUIRE(Cin == w.cin, "conv: channel mismatch");
+    Tensor o = new_tensor(w.cout, a.H, a.W);
+    if (dry_) return o;
+    ConvArgs ca{};
+    ca.src1 = a.p; ca.src2 = b ? b->p : nullptr; ca.C1 = a.C; ca.C2 = b ? b->C : 0;
+    ca.bias = bias; ca.bias2 = bias2; ca.bias2_bstride = ctl.bias_bstride; ca.bias2_sstride = ctl.bias_sstride;
+    ca.step_ptr = bias2 ? ctl.step_ptr : nullptr;
+    ca.in_scale = xf.scale; ca.in_shift = xf.shift; ca.in_act = xf.act;
+    ca.res = res; ca.out_scale = out_scale; ca.out = o.p; ca.Cout = w.cout; ca.B = B_; ca.H = a.H; ca.W = a.W;
+    const int kc = (w.ks == 3) ? 8 : 32;
+    tock();
+    const double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
+    if (w.packed && (ca.C2 == 0 || ca.C1 % kc == 0)) {
+      ConvPlan pl{w.co_t, a.H >= 8 ? 8 : 4, true};
+      ca.w = w.packed;
+      launch_conv_mfma(ca, w.ks, pl, stream_);
+      tick(w.ks == 3 ? TC_CONV3 : TC_CONV1, fl);
+    } else {
+      ca.w = w.oihw;
+      launch_conv_direct(ca, w.ks, stream_);
+      tick(TC_DIRECT, fl);
+    }
+    return o;
+  }
+
+  Tensor fir(const Tensor& a, bool up, const Xform& xf) {
+    Tensor o = up ? new_tensor(a.C, a.H * 2, a.W * 2) : new_tensor(a.C, a.H / 2, a.W / 2);
+    if (dry_) return o;
+    FirArgs fa{a.p, o.p, xf.scale, xf.shift, xf.act, B_ * a.C, a.H, a.W};
+    tock();
+    if (up) DRT_LAUNCH(fir_up2_kernel, dim3((a.H * a.W + 255) / 256, B_ * a.C), dim3(256), stream_, fa);
+    else DRT_LAUNCH(fir_down2_kernel, dim3(((a.H / 2) * (a.W / 2) + 255) / 256, B_ * a.C), dim3(256), stream_, fa);
+    tick(TC_FIR, 0.0);
+    return o;
+  }
+
+  // ResnetBlockBigGANpp.forward (layerspp.py:242-274).  Inputs stay owned by the caller.
+  Tensor res_block(const Mod& m, Tensor& a, Tensor* b, const FwdCtl& ctl) {
+    const ResW& r = res_.at(m.idx);
+    float *sc0, *sh0, *sc1, *sh1;
+    gn_coeffs(a, b, r.g0w, r.g0b, &sc0, &sh0);
+    Xform x0{sc0, sh0, 1};
+    const float* temb = ctl.bias_table ? ctl.bias_table + r.temb_off : nullptr;
+    Tensor h, xs;       // xs: resampled shortcut input (only for up/down)
+    bool have_xs = false;
+    if (m.up || m.down) {
+      SG_REQUIRE(b == nullptr, "resample block with concat input");
+      Tensor hr = fir(a, m.up, x0);
+      xs = fir(a, m.up, Xform{});
+      have_xs = true;
+      h = conv(r.c0, hr, nullptr, Xform{}, nullptr, temb, nullptr, 1.f, ctl);
+      drop(hr);
+    } else {
+      h = conv(r.c0, a, b, x0, nullptr, temb, nullptr, 1.f, ctl);
+    }
+    arena_.release(sc0); arena_.release(sh0);
+    gn_coeffs(h, nullptr, r.g1w, r.g1b, &sc1, &sh1);
+    Xform x1{sc1, sh1, 1};
+    Tensor out;
+    const float inv_sqrt2 = 0.70710678118654752440f;
+    if (r.has_c2) {
+      Tensor sh_t = have_xs ? conv(r.c2, xs, nullptr, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl)
+                            : conv(r.c2, a, b, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl);
+      out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, sh_t.p, inv_sqrt2, ctl);
+      drop(sh_t);
+    } else {
+      SG_REQUIRE(b == nullptr, "identity shortcut with concat input");
+      out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, a.p, inv_sqrt2, ctl);
+    }
+    if (have_xs) drop(xs);
+    drop(h);
+    arena_.release(sc1); arena_.release(sh1);
+    return out;
+  }
+
+  // AttnBlockpp.forward (layerspp.py:75-91)
+  Tensor attn_block(const Mod& m, Tensor& x, const FwdCtl& ctl) {
+    const AttnW& w = attn_.at(m.idx);
+    float *sc, *sh;
+    gn_coeffs(x, nullptr, w.gw, w.gb, &sc, &sh);
+    Tensor qkv = conv(w.qkv, x, nullptr, Xform{sc, sh, 0}, w.qkv.bias, nullptr, nullptr, 1.f, ctl);
+    arena_.release(sc); arena_.release(sh);
+    Tensor o = new_tensor(x.C, x.H, x.W);
+    if (!dry_) {
+      AttnArgs aa{qkv.p, o.p, B_, x.C, x.H * x.W, 1.0f / sqrtf((float)x.C)};
+      tock();
+      SG_REQUIRE(launch_attn_core(aa, stream_), "attention: unsupported channel count");
+      tick(TC_ATTN, 4.0 * B_ * (double)x.C * (x.H * x.W) * (double)(x.H * x.W));
+    }
+    drop(qkv);
+    Tensor out = conv(w.proj, o, nullptr, Xform{}, w.proj.bias, nullptr, x.p, 0.70710678118654752440f, ctl);
+    drop(o);
+    return out;
+  }
+
+  // NCSNpp.forward (ncsnpp.py:256-419) / NCSNpp_48k.forward
+  void run_forward(const float2* x, long long xbs, const float2* y, long long ybs, float2* out, int B, int F, int T,
+                   const FwdCtl& ctl) {
+    B_ = B;
+    const NetCfg& c = cfg_;
+    const int L = c.n_levels;
+    size_t mi = 3;
+    auto next = [&]() -> const Mod& { SG_REQUIRE(mi < layout_.size(), "layout exhausted"); return layout_[mi++]; };
+    const int FT = F * T;
+
+    Tensor xr = new_tensor(4, F, T);
+    if (!dry_) { tock(); DRT_LAUNCH(entry_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, x, xbs, y, ybs, xr.p, FT); tick(TC_MISC, 0.0); }
+    std::vector<Tensor> hs;
+    {
+      const Mod& m = next();
+      const ConvW& w = conv_.at(m.idx);
+      hs.push_back(conv(w, xr, nullptr, Xform{}, w.bias, nullptr, nullptr, 1.f, ctl));
+    }
+    Tensor pyr_in = xr;   // input pyramid (ncsnpp.py:293-296); released at the end / when replaced
+    bool pyr_in_is_xr = true;
+    for (int l = 0; l < L; ++l) {
+      for (int rb = 0; rb < c.num_res_blocks; ++rb) {
+        const Mod& m = next();
+        Tensor h = res_block(m, hs.back(), nullptr, ctl);
+        if (cfg_has_attn(c, h.H)) {
+          const Mod& ma = next();
+          Tensor h2 = attn_block(ma, h, ctl);
+          drop(h);
+          h = h2;
+        }
+        hs.push_back(h);
+      }
+      if (l != L - 1) {
+        const Mod& m = next();
+        Tensor h = res_block(m, hs.back(), nullptr, ctl);
+        if (c.progressive_input == 1) {
+          const Mod& mc = next();
+          Tensor np = fir(pyr_in, false, Xform{});
+          if (!pyr_in_is_xr) drop(pyr_in);
+          pyr_in = np; pyr_in_is_xr = false;
+          const ConvW& w = conv_.at(mc.idx);
+          Tensor h2 = conv(w, pyr_in, nullptr, Xform{}, w.bias, nullptr, h.p, 1.f, ctl);
+          drop(h);
+          h = h2;
+        }
+        hs.push_back(h);
+      }
+    }
+    if (!pyr_in_is_xr) drop(pyr_in);
+    drop(xr);
+
+    Tensor h = hs.back();   // not popped: still referenced by the skip stack (ncsnpp.py:337)
+    {
+      const Mod& m1 = next(); Tensor a = res_block(m1, h, nullptr, ctl);
+      const Mod& m2 = next(); Tensor b2 = attn_block(m2, a, ctl); drop(a);
+      const Mod& m3 = next(); h = res_block(m3, b2, nullptr, ctl); drop(b2);
+    }
+    Tensor pyramid; bool have_pyr = false;
+    for (int l = L - 1; l >= 0; --l) {
+      for (int rb = 0; rb < c.num_res_blocks + 1; ++rb) {
+        const Mod& m = next();
+        Tensor skip = hs.back(); hs.pop_back();
+        Tensor o = res_block(m, h, &skip, ctl);
+        drop(h); drop(skip);
+        h = o;
+      }
+      if (cfg_has_attn(c, h.H)) {
+        const Mod& ma = next();
+        Tensor h2 = attn_block(ma, h, ctl);
+        drop(h); h = h2;
+      }
+      if (c.progressive == 1) {
+        const Mod& mg = next(); const Mod& mc = next();
+        float *sc, *sh;
+        gn_coeffs(h, nullptr, gn_.at(mg.idx).first, gn_.at(mg.idx).second, &sc, &sh);
+        const ConvW& w = conv_.at(mc.idx);
+        Tensor up; bool have_up = false;
+        if (have_pyr) { up = fir(pyramid, true, Xform{}); have_up = true; drop(pyramid); }
+        pyramid = conv(w, h, nullptr, Xform{sc, sh, 1}, w.bias, nullptr, have_up ? up.p : nullptr, 1.f, ctl);
+        have_pyr = true;
+        if (have_up) drop(up);
+        arena_.release(sc); arena_.release(sh);
+      }
+      if (l != 0) {
+        const Mod& m = next();
+        Tensor o = res_block(m, h, nullptr, ctl);
+        drop(h); h = o;
+      }
+    }
+    SG_REQUIRE(hs.empty(), "skip stack not empty");
+    Tensor h4;
+    if (c.progressive == 1) { h4 = pyramid; drop(h); }
+    else {
+      const Mod& mg = next(); const Mod& mc = next();
+      float *sc, *sh;
+      gn_coeffs(h, nullptr, gn_.at(mg.idx).first, gn_.at(mg.idx).second, &sc, &sh);
+      const ConvW& w = conv_.at(mc.idx);
+      h4 = conv(w, h, nullptr, Xform{sc, sh, 1}, w.bias, nullptr, nullptr, 1.f, ctl);
+      arena_.release(sc); arena_.release(sh);
+      drop(h);
+    }
+    SG_REQUIRE(mi == layout_.size(), "forward did not consume every module");
+    if (!dry_) {
+      ExitArgs ea{h4.p, Wp("output_layer.weight"), Wp("output_layer.bias"), ctl.tvals, ctl.t_bstride, ctl.t_sstride, ctl.step_ptr,
+                  c.variant == 1 ? 1 : 0, c.scale_by_sigma, ctl.sign, out, FT};
+      tock();
+      DRT_LAUNCH(exit_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, ea);
+      tick(TC_MISC, 0.0);
+      check_launch();
+    }
+    drop(h4);
+  }
+
+  struct GraphKey {
+    int B, F, T, corr, ncorr, pred, pf; const void* y; const void* noise; unsigned long long seed; float theta; int dps;
+    bool operator==(const GraphKey& o) const {
+      return B == o.B && F == o.F && T == o.T && corr == o.corr && ncorr == o.ncorr && pred == o.pred && pf == o.pf && y == o.y &&
+             noise == o.noise && seed == o.seed && theta == o.theta && dps == o.dps;
+    }
+  };
+
+  int device_;
+  drt::stream_t stream_;
+  NetCfg cfg_;
+  std::vector<Mod> layout_;
+  std::map<std::string, const float*> W_;
+  float* blob_ = nullptr; size_t blob_elems_ = 0;
+  std::map<int, ResW> res_;
+  std::map<int, AttnW> attn_;
+  std::map<int, ConvW> conv_;
+  std::map<int, std::pair<const float*, const float*>> gn_;
+  DenseDesc* dense_descs_ = nullptr; int n_dense_ = 0; int tot_temb_ = 0;
+  bool weights_ready_ = false;
+  std::vector<void*> owned_;
+  std::map<int, const float2*> twiddles_;
+
+  Arena arena_; char* arena_base_ = nullptr; size_t arena_cap_ = 0;
+  bool dry_ = false;
+  int B_ = 0, shape_B_ = 0, shape_F_ = 0, shape_T_ = 0;
+  float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr; size_t samp_n_ = 0;
+  int* step_ctr_ = nullptr;
+  float *temb_act_ = nullptr, *bias_table_ = nullptr, *step_table_ = nullptr, *tsteps_ = nullptr; int temb_rows_ = 0;
+  drt::graph_t graph_{}; bool graph_valid_ = false; GraphKey graph_key_{};
+  int nfe_ = 0;
+  bool prof_ = false, ev_init_ = false; drt::event_t ev_a_{}, ev_b_{}; float prof_ms_[TC_COUNT]; double prof_flops_[TC_COUNT];
+};
+
+}  // namespace sgmse

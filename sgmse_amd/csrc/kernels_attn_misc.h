@@ -1,0 +1,331 @@
+// Self-attention core (MFMA), time-embedding MLP, network entry/exit and the sampler's element-wise updates.
+#pragma once
+#include <sgmse_devrt.h>
+#include "kernels_conv.h"
+#include "kernels_norm_fir.h"
+
+namespace sgmse {
+
+// ------------------------------------------------------------------------------------------------------
+// Attention core of AttnBlockpp (reference layerspp.py:82-88):
+//   w[s,r] = softmax_r( sum_c q[c,s] k[c,r] * C^-1/2 ),  o[c,s] = sum_r w[s,r] v[c,r]
+// qkv: [B][3C][S] (q | k | v along channels, S = H*W contiguous), out: [B][C][S].
+// One workgroup = 32 queries; its 4 waves take key tiles round-robin with private online-softmax state and are
+// merged through LDS at the end.  Both contractions run on v_mfma_f32_32x32x2_f32:
+//   QK^T:  D[i=key][j=query]  A = k[c][key] (lane = key), B = q[c][query] (lane = query)  -> 128-B coalesced loads
+//   P.V :  D[i=chan][j=query]  B operand of k-step r IS accumulator register r of the score fragment
+//          (key(r,kh) = (r&3)+8*(r>>2)+4*kh is exactly the key the lane holds), so P never leaves registers.
+struct AttnArgs { const float* qkv; float* out; int B, C, S; float scale; };
+
+template <int CF>
+__global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs p) {
+  constexpr int C = CF * 32;
+  __shared__ float s_O[C * 32];
+  __shared__ float s_m[4][32];
+  __shared__ float s_l[4][32];
+  __shared__ float s_lt[32];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+  const int S = p.S;
+  const int b = blockIdx.y, s0 = blockIdx.x * 32;
+  const float* q = p.qkv + (size_t)b * 3 * C * S;
+  const float* k = q + (size_t)C * S;
+  const float* v = k + (size_t)C * S;
+  const int nkt = (S + 31) / 32;
+  const bool qok = (s0 + l31) < S;
+  const float NEG_INF = -INFINITY;
+
+  float m = NEG_INF, lsum = 0.f;
+  f32x16 O[CF];
+#pragma unroll
+  for (int f = 0; f < CF; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[f][r] = 0.f;
+
+  for (int kt = wave; kt < nkt; kt += 4) {
+    const int r0 = kt * 32;
+    const bool kok = (r0 + l31) < S;
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll 8
+    for (int c2 = 0; c2 < C / 2; ++c2) {
+      const int c = 2 * c2 + kh;
+      const float a = kok ? k[(size_t)c * S + r0 + l31] : 0.f;
+      const float bq = qok ? q[(size_t)c * S + s0 + l31] : 0.f;
+      sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, sc, 0, 0, 0);
+    }
+    float mx = NEG_INF;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const float val = (key < S) ? sc[r] * p.scale : NEG_INF;
+      sc[r] = val;
+      mx = fmaxf(mx, val);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = expf(m - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = expf(sc[r] - m_new);
+      sc[r] = pr;
+      psum += pr;
+    }
+    psum += __shfl_xor(psum, 32);
+    lsum = lsum * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int f = 0; f < CF; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[f][r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const float bp = sc[r];
+#pragma unroll
+      for (int f = 0; f < CF; ++f) {
+        const float a = (key < S) ? v[(size_t)(f * 32 + l31) * S + key] : 0.f;
+        O[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp, O[f], 0, 0, 0);
+      }
+    }
+  }
+
+  if (kh == 0) { s_m[wave][l31] = m; s_l[wave][l31] = lsum; }
+  __syncthreads();
+  float mstar = fmaxf(fmaxf(s_m[0][l31], s_m[1][l31]), fmaxf(s_m[2][l31], s_m[3][l31]));
+  const float fac = expf(m - mstar);
+  if (wave == 0 && kh == 0) {
+    float lt = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) lt += s_l[w][l31] * expf(s_m[w][l31] - mstar);
+    s_lt[l31] = lt;
+  }
+#pragma unroll
+  for (int f = 0; f < CF; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[f][r] *= fac;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int f = 0; f < CF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (w == 0) s_O[ch * 32 + l31] = O[f][r];
+          else s_O[ch * 32 + l31] += O[f][r];
+        }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < C * 32; e += 256) {
+    const int ch = e >> 5, j = e & 31;
+    if (s0 + j < S) p.out[((size_t)b * C + ch) * S + s0 + j] = s_O[e] / s_lt[j];
+  }
+}
+
+inline bool launch_attn_core(const AttnArgs& a, drt::stream_t st) {
+  dim3 grid((a.S + 31) / 32, a.B, 1);
+  switch (a.C) {
+    case 32: DRT_LAUNCH((attn_core_kernel<1>), grid, dim3(256), st, a); return true;
+    case 64: DRT_LAUNCH((attn_core_kernel<2>), grid, dim3(256), st, a); return true;
+    case 128: DRT_LAUNCH((attn_core_kernel<4>), grid, dim3(256), st, a); return true;
+    case 256: DRT_LAUNCH((attn_core_kernel<8>), grid, dim3(256), st, a); return true;
+    default: return false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Time embedding (reference ncsnpp.py:265-284, layerspp.py:39-41): Fourier features of log t, Linear, SiLU, Linear;
+// output is SiLU(temb) (every consumer applies act(temb) first, layerspp.py:263).  One workgroup per t value.
+// log / sin / cos are evaluated in fp64 and rounded once so they agree with any correctly-rounded fp32 libm.
+struct TembArgs {
+  const float* t; int nt;
+  const float* Wf; const float* w1; const float* b1; const float* w2; const float* b2;
+  int nf;          // Fourier size; emb = 2*nf, hidden = 4*nf
+  float* act_out;  // [nt][4*nf]
+};
+
+__global__ __launch_bounds__(256) void temb_mlp_kernel(TembArgs p) {
+  __shared__ float s_emb[512];
+  __shared__ float s_h[1024];
+  const int row = blockIdx.x, nf = p.nf, ne = 2 * nf, nh = 4 * nf;
+  const float logt = (float)log((double)p.t[row]);
+  for (int i = threadIdx.x; i < nf; i += 256) {
+    float pr = logt * p.Wf[i];
+    pr = pr * 2.0f;
+    pr = pr * 3.14159265358979323846f;
+    s_emb[i] = (float)sin((double)pr);
+    s_emb[nf + i] = (float)cos((double)pr);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < nh; o += 256) {
+    float acc = 0.f;
+    const float* wr = p.w1 + (size_t)o * ne;
+    for (int i = 0; i < ne; ++i) acc = fmaf(wr[i], s_emb[i], acc);
+    s_h[o] = silu_f(acc + p.b1[o]);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < nh; o += 256) {
+    float acc = 0.f;
+    const float* wr = p.w2 + (size_t)o * nh;
+    for (int i = 0; i < nh; ++i) acc = fmaf(wr[i], s_h[i], acc);
+    p.act_out[(size_t)row * nh + o] = silu_f(acc + p.b2[o]);
+  }
+}
+
+// All per-ResBlock Dense_0 projections (layerspp.py:262-263) in one launch, with Conv_0's bias folded in:
+//   table[row][off + co] = Dense_0.b[co] + Conv_0.bias[co] + sum_i Dense_0.W[co][i] * act[row][i]
+struct DenseDesc { const float* W; const float* b; const float* cb; int cout; int off; };
+
+__global__ __launch_bounds__(256) void temb_dense_kernel(const DenseDesc* descs, const float* act, int nh, float* table,
+                                                         int row_stride) {
+  __shared__ float s_a[1024];
+  const DenseDesc d = descs[blockIdx.x];
+  const int row = blockIdx.y;
+  for (int i = threadIdx.x; i < nh; i += 256) s_a[i] = act[(size_t)row * nh + i];
+  __syncthreads();
+  for (int co = threadIdx.x; co < d.cout; co += 256) {
+    float acc = 0.f;
+    const float* wr = d.W + (size_t)co * nh;
+    for (int i = 0; i < nh; ++i) acc = fmaf(wr[i], s_a[i], acc);
+    table[(size_t)row * row_stride + d.off + co] = acc + d.b[co] + d.cb[co];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Network entry (ncsnpp.py:262-263): complex x_t, y -> real [B][4][F*T] = (x.re, x.im, y.re, y.im).
+__global__ __launch_bounds__(256) void entry_kernel(const float2* x, long long xbs, const float2* y, long long ybs,
+                                                    float* xr, int FT) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= FT) return;
+  const int b = blockIdx.y;
+  const float2 xv = x[(size_t)b * xbs + i], yv = y[(size_t)b * ybs + i];
+  float* o = xr + (size_t)b * 4 * FT + i;
+  o[0] = xv.x; o[FT] = xv.y; o[2 * (size_t)FT] = yv.x; o[3 * (size_t)FT] = yv.y;
+}
+
+// Network exit (ncsnpp.py:402-419 / ncsnpp_48k.py:414-421) fused with ScoreModel.forward's sign (model.py:309):
+//   ncsnpp    : h = h4 / t ; o = conv1x1(4->2)(h)        ncsnpp_48k: o = conv1x1(h4) ; o = o / t
+//   out = sign * complex(o0, o1)
+struct ExitArgs {
+  const float* h4; const float* ow; const float* ob;
+  const float* tvals; int t_bstride, t_sstride; const int* step_ptr;
+  int conv_first, scale_by_t; float sign;
+  float2* out; int FT;
+};
+
+__global__ __launch_bounds__(256) void exit_kernel(ExitArgs p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.FT) return;
+  const int b = blockIdx.y;
+  const int step = p.step_ptr ? *p.step_ptr : 0;
+  const float t = p.tvals[(size_t)step * p.t_sstride + (size_t)b * p.t_bstride];
+  const float* h = p.h4 + (size_t)b * 4 * p.FT + i;
+  float hv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) hv[c] = h[(size_t)c * p.FT];
+  if (p.scale_by_t && !p.conv_first) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hv[c] = hv[c] / t;
+  }
+  float o[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc = fmaf(p.ow[k * 4 + c], hv[c], acc);
+    o[k] = acc + p.ob[k];
+  }
+  if (p.scale_by_t && p.conv_first) { o[0] = o[0] / t; o[1] = o[1] / t; }
+  p.out[(size_t)b * p.FT + i] = make_float2(p.sign * o[0], p.sign * o[1]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Sampler element-wise updates (reference sdes.py:224-229, correctors.py:75-79, predictors.py:61-64 over
+// sdes.py:72-89,130-135).  Per-step scalars come from a device table built by the host with the reference's own
+// fp32 expressions; the step index is read from a device counter so one captured graph serves every step.
+enum { SC_T = 0, SC_DT = 1, SC_ALD_EPS = 2, SC_ALD_NOISE = 3, SC_G = 4, SC_G2 = 5, SC_STRIDE = 8 };
+
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+// complex standard normal (Re, Im ~ N(0, 1/2)), what torch.randn_like gives for complex64
+__device__ __forceinline__ float2 philox_cnormal(unsigned long long seed, unsigned long long idx, uint32_t draw) {
+  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = draw, c3 = 0x5367534du;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  const float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float rad = sqrtf(-logf(u1));  // sqrt(-2 ln u) * sqrt(1/2)
+  float sn, cs;
+  sincosf(6.283185307179586f * u2, &sn, &cs);
+  return make_float2(rad * cs, rad * sn);
+}
+
+struct SamplerArgs {
+  float2* x; float2* x_mean; const float2* y; const float2* score;
+  const float2* noise;       // replayed noise [ndraws][B*FT] or null (Philox)
+  unsigned long long seed;
+  const float* table; const int* step_ptr;
+  int draw_base, draw_per_step;  // draw index = draw_base + step*draw_per_step
+  float theta, score_w;     // score_w: 1 (reverse SDE) or 0.5 (probability flow)
+  int add_noise;
+  float std1;               // prior: std(T=1)
+  int n;                    // B*FT
+};
+
+__device__ __forceinline__ float2 sampler_noise(const SamplerArgs& p, int i, int draw) {
+  if (p.noise) return p.noise[(size_t)draw * p.n + i];
+  return philox_cnormal(p.seed, (unsigned long long)i, (uint32_t)draw);
+}
+
+__global__ __launch_bounds__(256) void sampler_prior_kernel(SamplerArgs p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const float2 z = sampler_noise(p, i, p.draw_base);
+  const float2 yv = p.y[i];
+  p.x[i] = make_float2(yv.x + z.x * p.std1, yv.y + z.y * p.std1);
+}
+
+__global__ __launch_bounds__(256) void sampler_ald_kernel(SamplerArgs p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const int step = *p.step_ptr;
+  const float* tb = p.table + (size_t)step * SC_STRIDE;
+  const float eps = tb[SC_ALD_EPS], ns = tb[SC_ALD_NOISE];
+  const float2 z = sampler_noise(p, i, p.draw_base + step * p.draw_per_step);
+  const float2 xv = p.x[i], g = p.score[i];
+  const float2 xm = make_float2(xv.x + eps * g.x, xv.y + eps * g.y);
+  p.x_mean[i] = xm;
+  p.x[i] = make_float2(xm.x + z.x * ns, xm.y + z.y * ns);
+}
+
+__global__ __launch_bounds__(256) void sampler_revdiff_kernel(SamplerArgs p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const int step = *p.step_ptr;
+  const float* tb = p.table + (size_t)step * SC_STRIDE;
+  const float dt = tb[SC_DT], G = tb[SC_G], G2 = tb[SC_G2] * p.score_w;
+  const float2 xv = p.x[i], yv = p.y[i], g = p.score[i];
+  const float fx = (p.theta * (yv.x - xv.x)) * dt - G2 * g.x;
+  const float fy = (p.theta * (yv.y - xv.y)) * dt - G2 * g.y;
+  const float2 xm = make_float2(xv.x - fx, xv.y - fy);
+  p.x_mean[i] = xm;
+  if (p.add_noise) {
+    const float2 z = sampler_noise(p, i, p.draw_base + step * p.draw_per_step);
+    p.x[i] = make_float2(xm.x + G * z.x, xm.y + G * z.y);
+  } else {
+    p.x[i] = xm;
+  }
+}
+
+__global__ void step_set_kernel(int* step, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *step = v; }
+__global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step = *step + 1; }
+
+}  // namespace sgmse

@@ -1,0 +1,193 @@
+// GroupNorm statistics / affine and FIR resampling kernels (HBM-bound class).
+//
+// GroupNorm: nn.GroupNorm(min(C//4,32), C, eps=1e-6) of reference layerspp.py:67,219,231 and ncsnpp.py:218,230.
+//   gn_chan_stats  : per-(b,c) plane sum and sum of squares (wave-shuffle + LDS tree), virtual concat of 2 sources
+//   gn_finalize    : per-(b,group) mean / rstd (fp64 combine of the channel partials) folded with gamma/beta into
+//                    scale[b][c], shift[b][c]; consumers (conv loaders, FIR kernels, gn_apply) evaluate x*scale+shift
+//   gn_apply       : standalone act(x*scale+shift) (op-level API / tests; the network fuses this into consumers)
+// FIR: upfirdn2d with the separable [1,3,3,1] kernel (reference up_or_down_sampling.py:195-257, op/upfirdn2d.py,
+//   op/upfirdn2d_kernel.cu modes 3 and 5) in closed form, optional fused producer
+//   act(x*scale+shift) with zero padding applied after it; upfirdn2d_generic covers every other
+//   (kernel, up, down, pad) of the native op's contract.
+#pragma once
+#include <sgmse_devrt.h>
+#include "kernels_conv.h"
+
+namespace sgmse {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// grid = B*C blocks of 256 threads; stats[(b*C+c)*2 + {0,1}] = {sum, sumsq}
+__global__ __launch_bounds__(256) void gn_chan_stats_kernel(const float* src1, const float* src2, int C1, int C2, int HW,
+                                                            float* stats) {
+  __shared__ float s_a[4];
+  __shared__ float s_b[4];
+  const int C = C1 + C2;
+  const int b = blockIdx.x / C, c = blockIdx.x % C;
+  const float* plane = (c < C1) ? src1 + (size_t)(b * C1 + c) * HW : src2 + (size_t)(b * C2 + (c - C1)) * HW;
+  float s = 0.f, q = 0.f;
+  if ((HW & 3) == 0) {
+    const float4* p4 = reinterpret_cast<const float4*>(plane);
+    for (int i = threadIdx.x; i < HW / 4; i += 256) {
+      const float4 v = p4[i];
+      s += (v.x + v.y) + (v.z + v.w);
+      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += 256) { const float v = plane[i]; s += v; q += v * v; }
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = s; s_b[threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[(size_t)blockIdx.x * 2 + 0] = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+    stats[(size_t)blockIdx.x * 2 + 1] = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+  }
+}
+
+// grid = B blocks of 256 threads
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* stats, const float* gamma, const float* beta, int C,
+                                                          int G, int HW, float eps, float* scale, float* shift) {
+  const int b = blockIdx.x;
+  const int cpg = C / G;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+      s += (double)stats[((size_t)b * C + g * cpg + k) * 2 + 0];
+      q += (double)stats[((size_t)b * C + g * cpg + k) * 2 + 1];
+    }
+    const double n = (double)cpg * (double)HW;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float a = gamma[c] * rstd;
+    scale[(size_t)b * C + c] = a;
+    shift[(size_t)b * C + c] = beta[c] - (float)mean * a;
+  }
+}
+
+// out = act(x*scale+shift); grid = (ceil(HW/1024), B*C)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* src1, const float* src2, int C1, int C2, int HW,
+                                                       const float* scale, const float* shift, int act, float* out) {
+  const int C = C1 + C2;
+  const int bc = blockIdx.y, b = bc / C, c = bc % C;
+  const float* plane = (c < C1) ? src1 + (size_t)(b * C1 + c) * HW : src2 + (size_t)(b * C2 + (c - C1)) * HW;
+  float* o = out + (size_t)bc * HW;
+  const float a = scale[bc], s = shift[bc];
+  const int base = blockIdx.x * 1024;
+  for (int k = 0; k < 4; ++k) {
+    const int i = base + k * 256 + threadIdx.x;
+    if (i < HW) {
+      float v = plane[i] * a + s;
+      if (act) v = silu_f(v);
+      o[i] = v;
+    }
+  }
+}
+
+struct FirArgs {
+  const float* src; float* out;
+  const float* in_scale; const float* in_shift;  // [B*C] or null
+  int in_act;
+  int BC, H, W;  // input plane geometry
+};
+
+__device__ __forceinline__ float fir_fetch(const FirArgs& p, const float* plane, int y, int x, float a, float s) {
+  if (y < 0 || y >= p.H || x < 0 || x >= p.W) return 0.f;
+  float v = plane[y * p.W + x];
+  if (p.in_scale) { v = v * a + s; if (p.in_act) v = silu_f(v); }
+  return v;
+}
+
+// FIR /2: out[i][j] = sum_{a,b} k[a]k[b] x[2i+a-1][2j+b-1], k=[1,3,3,1]/8.  grid = (ceil(Ho*Wo/256), BC)
+__global__ __launch_bounds__(256) void fir_down2_kernel(FirArgs p) {
+  const int Ho = p.H / 2, Wo = p.W / 2;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= Ho * Wo) return;
+  const int bc = blockIdx.y;
+  const int i = o / Wo, j = o - i * Wo;
+  const float* plane = p.src + (size_t)bc * p.H * p.W;
+  float a = 1.f, s = 0.f;
+  if (p.in_scale) { a = p.in_scale[bc]; s = p.in_shift[bc]; }
+  const float k[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+  float acc = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    float row = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) row += k[v] * fir_fetch(p, plane, 2 * i + u - 1, 2 * j + v - 1, a, s);
+    acc += k[u] * row;
+  }
+  p.out[(size_t)bc * Ho * Wo + o] = acc;
+}
+
+// FIR x2 (polyphase): out[2m] = (x[m-1] + 3x[m])/4, out[2m+1] = (3x[m] + x[m+1])/4 per axis.
+// One thread per input pixel -> 2x2 outputs.  grid = (ceil(H*W/256), BC)
+__global__ __launch_bounds__(256) void fir_up2_kernel(FirArgs p) {
+  const int H = p.H, W = p.W;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= H * W) return;
+  const int bc = blockIdx.y;
+  const int i = o / W, j = o - i * W;
+  const float* plane = p.src + (size_t)bc * H * W;
+  float a = 1.f, s = 0.f;
+  if (p.in_scale) { a = p.in_scale[bc]; s = p.in_shift[bc]; }
+  float v[3][3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int w = 0; w < 3; ++w) v[u][w] = fir_fetch(p, plane, i + u - 1, j + w - 1, a, s);
+  // horizontal pass for the three rows
+  float he[3], ho[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    he[u] = 0.25f * v[u][0] + 0.75f * v[u][1];
+    ho[u] = 0.75f * v[u][1] + 0.25f * v[u][2];
+  }
+  const int Wo = 2 * W;
+  float* out = p.out + (size_t)bc * 4 * H * W + (size_t)(2 * i) * Wo + 2 * j;
+  float2 r0 = make_float2(0.25f * he[0] + 0.75f * he[1], 0.25f * ho[0] + 0.75f * ho[1]);
+  float2 r1 = make_float2(0.75f * he[1] + 0.25f * he[2], 0.75f * ho[1] + 0.25f * ho[2]);
+  *reinterpret_cast<float2*>(out) = r0;
+  *reinterpret_cast<float2*>(out + Wo) = r1;
+}
+
+// Generic upfirdn2d (reference op/upfirdn2d.py:162-203 semantics): zero-insert by `up`, pad/crop, correlate with the
+// flipped kernel, decimate by `down`.  grid = (ceil(Ho*Wo/256), BC).
+struct UpfirdnArgs {
+  const float* src; const float* kern; float* out;
+  int BC, H, W, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnArgs p) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= p.Ho * p.Wo) return;
+  const int bc = blockIdx.y;
+  const int oy = o / p.Wo, ox = o - oy * p.Wo;
+  const float* plane = p.src + (size_t)bc * p.H * p.W;
+  float acc = 0.f;
+  for (int a = 0; a < p.kh; ++a) {
+    // position in the zero-inserted, padded signal
+    const int zy = oy * p.down_y + a - p.pad_y0;
+    if (zy < 0 || zy % p.up_y != 0) continue;
+    const int iy = zy / p.up_y;
+    if (iy >= p.H) continue;
+    for (int c = 0; c < p.kw; ++c) {
+      const int zx = ox * p.down_x + c - p.pad_x0;
+      if (zx < 0 || zx % p.up_x != 0) continue;
+      const int ix = zx / p.up_x;
+      if (ix >= p.W) continue;
+      acc += p.kern[(p.kh - 1 - a) * p.kw + (p.kw - 1 - c)] * plane[iy * p.W + ix];
+    }
+  }
+  p.out[(size_t)bc * p.Ho * p.Wo + o] = acc;
+}
+
+}  // namespace sgmse

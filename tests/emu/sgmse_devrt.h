@@ -1,0 +1,101 @@
+// CPU emulation of the small slice of the HIP device/runtime model that the sgmse_amd kernels use.
+//
+// TEST INFRASTRUCTURE ONLY.  This header shadows sgmse_amd/csrc/sgmse_devrt.h when the kernel sources are
+// compiled with g++ (-I tests/emu) into tests/emu/libsgmse_emu.so, so that the *same* kernel code (index maths,
+// LDS tiling, MFMA fragment layouts, wave shuffles, barriers) can be checked against the oracle in the build
+// container, which has no GPU.  The product library (libsgmse_hip.so) is built by hipcc with the real header and
+// never contains any of this.  Every workgroup runs as 64..1024 cooperative fibers on one OS thread; a wavefront
+// is 64 consecutive fibers; __syncthreads / wave collectives are fiber barriers.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <functional>
+#include <algorithm>
+
+#define SGMSE_EMULATOR 1
+
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+typedef float f32x16 __attribute__((vector_size(64)));
+typedef float f32x4 __attribute__((vector_size(16)));
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+
+namespace emu {
+struct Idx { unsigned x, y, z; };
+extern thread_local Idx t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void sync_block();
+float shfl_xor(float v, int mask);
+float shfl_idx(float v, int src_lane);
+f32x16 mfma_32x32x2(float a, float b, f32x16 c);
+f32x4 mfma_16x16x4(float a, float b, f32x4 c);
+}  // namespace emu
+
+#define threadIdx (emu::t_threadIdx)
+#define blockIdx (emu::t_blockIdx)
+#define blockDim (emu::t_blockDim)
+#define gridDim (emu::t_gridDim)
+
+static inline void __syncthreads() { emu::sync_block(); }
+static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return emu::shfl_xor(v, mask); }
+static inline float __shfl(float v, int lane, int width = 64) { (void)width; return emu::shfl_idx(v, lane); }
+static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) { return emu::mfma_32x32x2(a, b, c); }
+static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) { return emu::mfma_16x16x4(a, b, c); }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float atomicAdd(float* p, float v) {
+  uint32_t* ip = reinterpret_cast<uint32_t*>(p);
+  uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED), nw;
+  float f;
+  do { memcpy(&f, &old, 4); f += v; memcpy(&nw, &f, 4); } while (!__atomic_compare_exchange_n(ip, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  memcpy(&f, &old, 4);
+  return f;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+#define DRT_LAUNCH(kern, grid, block, stream, ...) \
+  do { (void)(stream); emu::launch((grid), (block), [=]() { kern(__VA_ARGS__); }); } while (0)
+
+namespace drt {
+typedef void* stream_t;
+struct event_t { double t; };
+struct graph_t { int dummy; };
+inline bool is_emulator() { return true; }
+inline const char* backend_name() { return "cpu-emulator(test-only)"; }
+inline int set_device(int) { return 0; }
+inline int malloc_dev(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? 0 : 1; }
+inline int free_dev(void* p) { free(p); return 0; }
+inline int memcpy_h2d(void* d, const void* s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
+inline int memcpy_d2h(void* d, const void* s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
+inline int memcpy_d2d(void* d, const void* s, size_t n, stream_t) { memmove(d, s, n); return 0; }
+inline int memset_dev(void* d, int v, size_t n, stream_t) { memset(d, v, n); return 0; }
+inline int stream_sync(stream_t) { return 0; }
+inline int last_error() { return 0; }
+inline const char* error_string(int) { return "emulator"; }
+double wall_ms();
+inline int event_create(event_t* e) { e->t = 0; return 0; }
+inline int event_destroy(event_t*) { return 0; }
+inline int event_record(event_t* e, stream_t) { e->t = wall_ms(); return 0; }
+inline int event_sync(event_t*) { return 0; }
+inline float event_elapsed_ms(const event_t& a, const event_t& b) { return float(b.t - a.t); }
+// graphs: not emulated (eager execution only)
+inline bool graphs_supported() { return false; }
+inline int graph_begin_capture(stream_t) { return 1; }
+inline int graph_end_capture(stream_t, graph_t*) { return 1; }
+inline int graph_launch(graph_t*, stream_t) { return 1; }
+inline int graph_destroy(graph_t*) { return 0; }
+inline int device_count() { return 1; }
+inline size_t device_mem_total() { return size_t(8) << 30; }
+}  // namespace drt
