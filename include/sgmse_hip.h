@@ -122,11 +122,14 @@ int sgmse_op_fir(sgmse_ctx* ctx, const float* x, float* out, int BC, int H, int 
 /* attention core of AttnBlockpp (layerspp.py:82-88): qkv fp32 [B][3C][S] -> out fp32 [B][C][S] */
 int sgmse_op_attention(sgmse_ctx* ctx, const float* qkv, float* out, int B, int C, int S);
 
-/* -- measurement: one eager forward with HIP events around every kernel class.  ms and flops are host arrays of
- *    SGMSE_NCLASS entries: conv3x3-mfma, conv1x1-mfma, conv-direct, groupnorm, fir, attention, misc.  synchronises */
-#define SGMSE_NCLASS 7
+/* -- measurement: one eager forward with HIP events (on the context's stream) around every kernel launch, summed per
+ *    kernel class.  ms, work and launches are host arrays of SGMSE_NCLASS entries:
+ *      0 conv3x3 MFMA, 128-channel x 256-pixel tile (the dominant kernel)   1 conv3x3 MFMA, other tiles
+ *      2 conv1x1 MFMA   3 direct (VALU) conv   4 groupnorm statistics   5 FIR resampling   6 attention core   7 entry/exit
+ *    work = algorithmic FLOPs (classes 0-3, 6) or algorithmic bytes (classes 4, 5, 7).  synchronises */
+#define SGMSE_NCLASS 8
 int sgmse_profile_forward(sgmse_ctx* ctx, const void* xy, const float* t, void* out, int B, int F, int T, float* ms,
-                          double* flops);
+                          double* work, int* launches);
 int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out);
 
 #ifdef __cplusplus

@@ -18,8 +18,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libsgmse_hip.so")
 
-SGMSE_NCLASS = 7
-CLASS_NAMES = ("conv3x3_mfma", "conv1x1_mfma", "conv_direct", "groupnorm", "fir", "attention", "misc")
+SGMSE_NCLASS = 8
+CLASS_NAMES = ("conv3x3_mfma_128x256", "conv3x3_mfma_other", "conv1x1_mfma", "conv_direct", "groupnorm_stats", "fir",
+               "attention", "entry_exit")
+CLASS_WORK_UNIT = ("flop", "flop", "flop", "flop", "byte", "byte", "flop", "byte")
 
 
 class NetCfgC(C.Structure):
@@ -61,7 +63,7 @@ _SIGS = {
     "sgmse_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I]),
     "sgmse_op_fir": (_I, [_P, _P, _P, _I, _I, _I, _I]),
     "sgmse_op_attention": (_I, [_P, _P, _P, _I, _I, _I]),
-    "sgmse_profile_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(C.c_double)]),
+    "sgmse_profile_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(_I)]),
     "sgmse_arena_bytes": (_I, [_P, C.POINTER(_LL)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
@@ -278,9 +280,11 @@ class Context:
         out = torch.empty((B, 1, F_, T), dtype=torch.complex64, device=self.device)
         ms = (_F * SGMSE_NCLASS)()
         fl = (C.c_double * SGMSE_NCLASS)()
+        nl = (_I * SGMSE_NCLASS)()
         self.use_current_stream()
-        self.check(self.lib.sgmse_profile_forward(self.h, xy.data_ptr(), t.data_ptr(), out.data_ptr(), B, F_, T, ms, fl))
-        return {n: (ms[i], fl[i]) for i, n in enumerate(CLASS_NAMES)}, out
+        self.check(self.lib.sgmse_profile_forward(self.h, xy.data_ptr(), t.data_ptr(), out.data_ptr(), B, F_, T, ms, fl, nl))
+        return {n: {"ms": ms[i], "work": fl[i], "unit": CLASS_WORK_UNIT[i], "launches": nl[i]}
+                for i, n in enumerate(CLASS_NAMES)}, out
 
     def arena_bytes(self) -> int:
         out = _LL(0)

@@ -164,9 +164,10 @@ int sgmse_op_attention(sgmse_ctx* ctx, const float* qkv, float* out, int B, int 
   return sg_guard(ctx, [&](sgmse::Engine& e) { e.op_attention(qkv, out, B, C, S); });
 }
 
-int sgmse_profile_forward(sgmse_ctx* ctx, const void* xy, const float* t, void* out, int B, int F, int T, float* ms, double* flops) {
-  SG_ARG(ctx, xy && t && out && ms && flops, "null pointer");
-  return sg_guard(ctx, [&](sgmse::Engine& e) { e.profile_forward((const float2*)xy, t, (float2*)out, B, F, T, ms, flops); });
+int sgmse_profile_forward(sgmse_ctx* ctx, const void* xy, const float* t, void* out, int B, int F, int T, float* ms, double* work,
+                          int* launches) {
+  SG_ARG(ctx, xy && t && out && ms && work && launches, "null pointer");
+  return sg_guard(ctx, [&](sgmse::Engine& e) { e.profile_forward((const float2*)xy, t, (float2*)out, B, F, T, ms, work, launches); });
 }
 
 int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out) {

@@ -472,13 +472,16 @@ class Engine {
   void sync() { SG_CHECK(drt::stream_sync(stream_)); }
 
   // per-kernel-class timing of one forward (eager, events on this stream); fills ms per class
-  enum { TC_CONV3 = 0, TC_CONV1, TC_DIRECT, TC_GN, TC_FIR, TC_ATTN, TC_MISC, TC_COUNT };
-  void profile_forward(const float2* xy, const float* t_dev, float2* out, int B, int F, int T, float* ms_out, double* flops_out) {
+  enum { TC_CONV3_BIG = 0, TC_CONV3, TC_CONV1, TC_DIRECT, TC_GN, TC_FIR, TC_ATTN, TC_MISC, TC_COUNT };
+  // work[] = algorithmic FLOPs for the conv/attention classes, algorithmic bytes (each operand read once, each result
+  // written once) for the HBM-bound classes (groupnorm statistics, FIR, misc)
+  void profile_forward(const float2* xy, const float* t_dev, float2* out, int B, int F, int T, float* ms_out, double* work_out,
+                       int* launches_out) {
     prof_ = true;
-    for (int i = 0; i < TC_COUNT; ++i) { prof_ms_[i] = 0.f; prof_flops_[i] = 0.0; }
+    for (int i = 0; i < TC_COUNT; ++i) { prof_ms_[i] = 0.f; prof_flops_[i] = 0.0; prof_n_[i] = 0; }
     forward_xy(xy, t_dev, out, B, F, T);
     prof_ = false;
-    for (int i = 0; i < TC_COUNT; ++i) { ms_out[i] = prof_ms_[i]; flops_out[i] = prof_flops_[i]; }
+    for (int i = 0; i < TC_COUNT; ++i) { ms_out[i] = prof_ms_[i]; work_out[i] = prof_flops_[i]; launches_out[i] = prof_n_[i]; }
   }
 
  private:
@@ -656,12 +659,13 @@ class Engine {
   // ---- op wrappers used by the forward ------------------------------------------------------------------------
   struct Xform { const float* scale = nullptr; const float* shift = nullptr; int act = 0; };
 
-  void tick(int cls, double flops) {
+  void tick(int cls, double work, int launches = 1) {
     if (!prof_) return;
     drt::event_record(&ev_b_, stream_);
     drt::event_sync(&ev_b_);
     prof_ms_[cls] += drt::event_elapsed_ms(ev_a_, ev_b_);
-    prof_flops_[cls] += flops;
+    prof_flops_[cls] += work;
+    prof_n_[cls] += launches;
   }
   void tock() { if (prof_) { if (!ev_init_) { drt::event_create(&ev_a_); drt::event_create(&ev_b_); ev_init_ = true; } drt::event_record(&ev_a_, stream_); } }
 
@@ -679,7 +683,7 @@ class Engine {
                  b ? b->C : 0, HW, stats);
       const int G = std::min(C / 4, 32);
       DRT_LAUNCH(gn_finalize_kernel, dim3(B_), dim3(256), stream_, (const float*)stats, gamma, beta, C, G, HW, 1e-6f, *sc, *sh);
-      tick(TC_GN, 0.0);
+      tick(TC_GN, 4.0 * B_ * (double)C * HW, 2);
     }
     arena_.release(stats);
   }
@@ -703,7 +707,7 @@ class Engine {
       ConvPlan pl{w.co_t, a.H >= 8 ? 8 : 4, true};
       ca.w = w.packed;
       launch_conv_mfma(ca, w.ks, pl, stream_);
-      tick(w.ks == 3 ? TC_CONV3 : TC_CONV1, fl);
+      tick(w.ks == 3 ? ((w.co_t == 128 && pl.rows == 8) ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else {
       ca.w = w.oihw;
       launch_conv_direct(ca, w.ks, stream_);
@@ -719,7 +723,7 @@ class Engine {
     tock();
     if (up) DRT_LAUNCH(fir_up2_kernel, dim3((a.H * a.W + 255) / 256, B_ * a.C), dim3(256), stream_, fa);
     else DRT_LAUNCH(fir_down2_kernel, dim3(((a.H / 2) * (a.W / 2) + 255) / 256, B_ * a.C), dim3(256), stream_, fa);
-    tick(TC_FIR, 0.0);
+    tick(TC_FIR, 4.0 * B_ * (double)a.C * (a.H * a.W + (double)o.H * o.W));
     return o;
   }
 
@@ -793,7 +797,7 @@ class Engine {
     const int FT = F * T;
 
     Tensor xr = new_tensor(4, F, T);
-    if (!dry_) { tock(); DRT_LAUNCH(entry_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, x, xbs, y, ybs, xr.p, FT); tick(TC_MISC, 0.0); }
+    if (!dry_) { tock(); DRT_LAUNCH(entry_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, x, xbs, y, ybs, xr.p, FT); tick(TC_MISC, 32.0 * B * FT); }
     std::vector<Tensor> hs;
     {
       const Mod& m = next();
@@ -889,7 +893,7 @@ class Engine {
                   c.variant == 1 ? 1 : 0, c.scale_by_sigma, ctl.sign, out, FT};
       tock();
       DRT_LAUNCH(exit_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, ea);
-      tick(TC_MISC, 0.0);
+      tick(TC_MISC, 24.0 * B * FT);
       check_launch();
     }
     drop(h4);
@@ -926,7 +930,7 @@ class Engine {
   float *temb_act_ = nullptr, *bias_table_ = nullptr, *step_table_ = nullptr, *tsteps_ = nullptr; int temb_rows_ = 0;
   drt::graph_t graph_{}; bool graph_valid_ = false; GraphKey graph_key_{};
   int nfe_ = 0;
-  bool prof_ = false, ev_init_ = false; drt::event_t ev_a_{}, ev_b_{}; float prof_ms_[TC_COUNT]; double prof_flops_[TC_COUNT];
+  bool prof_ = false, ev_init_ = false; drt::event_t ev_a_{}, ev_b_{}; float prof_ms_[TC_COUNT]; double prof_flops_[TC_COUNT]; int prof_n_[TC_COUNT];
 };
 
 }  // namespace sgmse

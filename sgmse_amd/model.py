@@ -1,0 +1,243 @@
+"""ScoreModel: the model facade of the enhancement path (reference sgmse/model.py:22-465, inference methods).
+
+A plain ``torch.nn.Module`` (pytorch_lightning / torch_ema are not needed for inference): builds the backbone and SDE
+from the registries, loads Lightning checkpoints (``state_dict`` with ``dnn.`` prefix, ``hyper_parameters``, ``ema``),
+swaps the EMA weights in on ``eval()`` as the reference does (model.py:111-125), and exposes ``forward``,
+``get_pc_sampler``, ``get_ode_sampler``, ``to_audio``, ``_stft/_istft/_forward_transform/_backward_transform`` and
+``enhance``.  Training-side methods (losses, steps, optimisers) are out of scope and raise.
+"""
+from __future__ import annotations
+
+import time
+import warnings
+from math import ceil
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import sampling
+from .backbones import BackboneRegistry
+from .data_module import SpecsDataModule
+from .sdes import SDERegistry
+from .util.other import pad_spec
+
+
+class ScoreModel(nn.Module):
+    _native_score_wrapper = True   # forward == -dnn(cat[x_t, y], t): the wrapper the fused HIP sampler implements
+
+    @staticmethod
+    def add_argparse_args(parser):
+        parser.add_argument("--lr", type=float, default=1e-4)
+        parser.add_argument("--ema_decay", type=float, default=0.999)
+        parser.add_argument("--t_eps", type=float, default=0.03)
+        parser.add_argument("--num_eval_files", type=int, default=20)
+        parser.add_argument("--loss_type", type=str, default="score_matching")
+        parser.add_argument("--sr", type=int, default=16000)
+        return parser
+
+    def __init__(self, backbone, sde, lr=1e-4, ema_decay=0.999, t_eps=0.03, num_eval_files=20, loss_type="score_matching",
+                 loss_weighting="sigma^2", network_scaling=None, c_in="1", c_out="1", c_skip="0", sigma_data=0.1,
+                 l1_weight=0.001, pesq_weight=0.0, sr=16000, data_module_cls=None, **kwargs):
+        super().__init__()
+        self.backbone = backbone
+        dnn_cls = BackboneRegistry.get_by_name(backbone)      # ValueError for unknown names
+        self.dnn = dnn_cls(**kwargs)
+        sde_cls = SDERegistry.get_by_name(sde)
+        self.sde = sde_cls(**kwargs)
+        self.lr, self.ema_decay, self.t_eps = lr, ema_decay, t_eps
+        self.loss_type, self.loss_weighting = loss_type, loss_weighting
+        self.l1_weight, self.pesq_weight = l1_weight, pesq_weight
+        self.network_scaling, self.c_in, self.c_out, self.c_skip, self.sigma_data = network_scaling, c_in, c_out, c_skip, sigma_data
+        self.num_eval_files, self.sr = num_eval_files, sr
+        self.hparams = dict(backbone=backbone, sde=sde, lr=lr, ema_decay=ema_decay, t_eps=t_eps, num_eval_files=num_eval_files,
+                            loss_type=loss_type, sr=sr, data_module_cls=data_module_cls, **kwargs)
+        data_module_cls = SpecsDataModule if data_module_cls is None else data_module_cls
+        self.data_module = data_module_cls(**kwargs, gpu=kwargs.get("gpus", 0) > 0)
+        # EMA bookkeeping (what torch_ema's store / copy_to / restore do for the reference, model.py:111-122)
+        self._ema_shadow: Optional[List[torch.Tensor]] = None
+        self._ema_stored: Optional[List[torch.Tensor]] = None
+        self._error_loading_ema = False
+
+    # -- checkpoints ---------------------------------------------------------------------------------------------
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, **overrides):
+        """Read a Lightning ``.ckpt`` written by the reference's train.py without
+        pytorch_lightning: ``hyper_parameters`` -> constructor, ``state_dict`` (keys ``dnn.*``) -> backbone,
+        ``ema`` -> shadow parameters used by ``eval()``."""
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        hp.update(overrides)
+        hp.pop("no_wandb", None)
+        model = cls(**hp)
+        sd = {k[len("dnn."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("dnn.")}
+        model.dnn.load_state_dict(sd, strict=strict)
+        model.on_load_checkpoint(ckpt)
+        if map_location is not None:
+            model.to(map_location)
+        return model
+
+    def on_load_checkpoint(self, checkpoint):
+        ema = checkpoint.get("ema", None)
+        if ema is None:
+            self._error_loading_ema = True
+            warnings.warn("EMA state_dict not found in checkpoint!")
+            return
+        shadow = [p.detach().clone().float() for p in ema["shadow_params"]]
+        params = list(self.dnn.parameters())
+        trainable = [p for p in params if p.requires_grad]
+        if len(shadow) == len(params):
+            self._ema_targets = params
+        elif len(shadow) == len(trainable):      # torch_ema tracks only requires_grad parameters
+            self._ema_targets = trainable
+        else:
+            self._error_loading_ema = True
+            warnings.warn(f"EMA has {len(shadow)} tensors but the backbone has {len(params)} parameters; ignoring EMA.")
+            return
+        self._ema_shadow = shadow
+
+    def train(self, mode=True, no_ema=False):
+        res = super().train(mode)
+        if not self._error_loading_ema and self._ema_shadow is not None:
+            if mode is False and not no_ema:
+                if self._ema_stored is None:
+                    self._ema_stored = [p.detach().clone() for p in self._ema_targets]
+                with torch.no_grad():
+                    for p, s in zip(self._ema_targets, self._ema_shadow):
+                        p.copy_(s.to(p.device))
+                self.dnn.mark_weights_changed()
+            elif self._ema_stored is not None:
+                with torch.no_grad():
+                    for p, s in zip(self._ema_targets, self._ema_stored):
+                        p.copy_(s.to(p.device))
+                self._ema_stored = None
+                self.dnn.mark_weights_changed()
+        return res
+
+    def eval(self, no_ema=False):
+        return self.train(False, no_ema=no_ema)
+
+    # -- training side: out of scope ---------------------------------------------------------------------------
+    def _loss(self, *a, **k):
+        raise NotImplementedError("training is outside the MI355X hot path (inference only)")
+
+    _step = training_step = validation_step = configure_optimizers = _loss
+
+    # -- score function (reference model.py:307-310, the branch every ncsnpp / ncsnpp_48k checkpoint takes) --------
+    def forward(self, x_t, y, t):
+        if self.backbone == "ncsnpp_v2":
+            raise NotImplementedError("ncsnpp_v2 (new-code branch, model.py:284-304) is a next-tier row, not built yet")
+        dnn_input = torch.cat([x_t, y], dim=1)
+        return -self.dnn(dnn_input, t)
+
+    # -- samplers (reference model.py:348-390) -----------------------------------------------------------------
+    def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, **kwargs):
+        N = self.sde.N if N is None else N
+        sde = self.sde.copy()
+        sde.N = N
+        kwargs = {"eps": self.t_eps, **kwargs}
+        if minibatch is None:
+            return sampling.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y, **kwargs)
+        M = y.shape[0]
+
+        def batched_sampling_fn():
+            samples, ns = [], []
+            for i in range(int(ceil(M / minibatch))):
+                y_mini = y[i * minibatch:(i + 1) * minibatch]
+                sample, n = sampling.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y_mini, **kwargs)()
+                samples.append(sample)
+                ns.append(n)
+            return torch.cat(samples, dim=0), ns
+        return batched_sampling_fn
+
+    def get_ode_sampler(self, y, N=None, minibatch=None, **kwargs):
+        N = self.sde.N if N is None else N
+        sde = self.sde.copy()
+        sde.N = N
+        kwargs = {"eps": self.t_eps, **kwargs}
+        if minibatch is None:
+            return sampling.get_ode_sampler(sde, self, y=y, **kwargs)
+        M = y.shape[0]
+
+        def batched_sampling_fn():
+            samples, ns = [], []
+            for i in range(int(ceil(M / minibatch))):
+                y_mini = y[i * minibatch:(i + 1) * minibatch]
+                sample, n = sampling.get_ode_sampler(sde, self, y=y_mini, **kwargs)()
+                samples.append(sample)
+                ns.append(n)
+            return torch.cat(samples, dim=0), ns     # (the reference returns only the last mini-batch: model.py:389)
+        return batched_sampling_fn
+
+    def get_sb_sampler(self, *a, **k):
+        raise NotImplementedError("the Schroedinger-bridge sampler is out of scope of this build")
+
+    # -- audio helpers (reference model.py:411-424) -----------------------------------------------------------
+    def to_audio(self, spec, length=None):
+        return self._istft(self._backward_transform(spec), length)
+
+    def _forward_transform(self, spec):
+        return self.data_module.spec_fwd(spec)
+
+    def _backward_transform(self, spec):
+        return self.data_module.spec_back(spec)
+
+    def _stft(self, sig):
+        return self.data_module.stft(sig)
+
+    def _istft(self, spec, length=None):
+        return self.data_module.istft(spec, length)
+
+    def _device(self):
+        return next(self.dnn.parameters()).device
+
+    def enhance(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=30, corrector_steps=1, snr=0.5,
+                timeit=False, **kwargs):
+        """One-call enhancement of a noisy waveform y [1, L] (reference model.py:426-465): normalise, STFT, spec_fwd,
+        zero-pad, sample, spec_back, iSTFT, renormalise; returns a NumPy array (and nfe, RTF with ``timeit``)."""
+        start = time.time()
+        dev = self._device()
+        T_orig = y.size(1)
+        norm_factor = y.abs().max().item()
+        y = y / norm_factor
+        Y = torch.unsqueeze(self._forward_transform(self._stft(y.to(dev))), 0)
+        Y = pad_spec(Y)
+        if self.sde.__class__.__name__ == "OUVESDE":
+            if self.sde.sampler_type == "pc":
+                sampler = self.get_pc_sampler(predictor, corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr,
+                                              intermediate=False, **kwargs)
+            elif self.sde.sampler_type == "ode":
+                sampler = self.get_ode_sampler(Y, N=N, **kwargs)
+            else:
+                raise ValueError("Invalid sampler type for SGMSE sampling: {}".format(sampler_type))
+        else:
+            raise ValueError("Invalid SDE type for speech enhancement: {}".format(self.sde.__class__.__name__))
+        sample, nfe = sampler()
+        x_hat = self.to_audio(sample.squeeze(), T_orig)
+        x_hat = x_hat * norm_factor
+        x_hat = x_hat.squeeze().cpu().numpy()
+        end = time.time()
+        if timeit:
+            return x_hat, nfe, (end - start) / (len(x_hat) / self.sr)
+        return x_hat
+
+    def enhance_batch(self, y, N=30, corrector="ald", corrector_steps=1, snr=0.5, pad_mode="zero_pad", noise=None, seed=None,
+                      predictor="reverse_diffusion", sampler_type="pc", use_graph=True):
+        """Batched form of enhancement.py:62-99 for B utterances of equal length: y float32 [B, L] on the model's device
+        -> enhanced float32 [B, L] (stays on the device).  Not in the reference (which loops files one by one)."""
+        dev = self._device()
+        y = y.to(dev)
+        T_orig = y.size(1)
+        norm = y.abs().amax(dim=1, keepdim=True)
+        Y = self._forward_transform(self._stft(y / norm)).unsqueeze(1)
+        Y = pad_spec(Y, mode=pad_mode)
+        if sampler_type == "pc":
+            sampler = self.get_pc_sampler(predictor, corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr, noise=noise,
+                                          seed=seed, use_graph=use_graph)
+        elif sampler_type == "ode":
+            sampler = self.get_ode_sampler(Y, N=N, noise=noise, seed=seed, use_graph=use_graph)
+        else:
+            raise ValueError(f"Sampler type {sampler_type} not supported")
+        sample, nfe = sampler()
+        x_hat = self.to_audio(sample[:, 0], T_orig) * norm
+        return x_hat, nfe

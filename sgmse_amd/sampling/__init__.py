@@ -1,0 +1,128 @@
+"""Sampler factories of the enhancement path (reference sgmse/sampling/__init__.py:26-143).
+
+``get_pc_sampler`` returns a zero-argument callable producing ``(sample, nfe)`` like the reference.  When the score
+function is a ``ScoreModel`` with a HIP backbone, the SDE is OUVE and the predictor/corrector pair has fused kernels
+('reverse_diffusion' | 'none'  x  'ald' | 'none'), the whole N-step loop runs inside the HIP library
+(sgmse_pc_sample: one hipGraph-captured predictor-corrector step replayed N times, per-step constants from a device
+table, Philox or replayed noise).  Any other combination falls back to the reference's Python loop over the registry
+classes, with every score evaluation still running on the HIP network.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ..sdes import OUVESDE
+from .correctors import Corrector, CorrectorRegistry
+from .predictors import Predictor, PredictorRegistry, ReverseDiffusionPredictor
+
+__all__ = ["PredictorRegistry", "CorrectorRegistry", "Predictor", "Corrector", "get_sampler", "get_pc_sampler",
+           "get_ode_sampler"]
+
+_NATIVE_PRED = ("reverse_diffusion", "none")
+_NATIVE_CORR = ("ald", "none")
+
+
+def _native_engine(score_fn, y):
+    """The HIP context behind ``score_fn`` if it is a ScoreModel on a HIP backbone using the plain score wrapper."""
+    dnn = getattr(score_fn, "dnn", None)
+    if dnn is None or not hasattr(dnn, "engine"):
+        return None
+    if getattr(score_fn, "_native_score_wrapper", False) is not True:
+        return None
+    return dnn.engine(y.device)
+
+
+def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=True, eps=3e-2, snr=0.1, corrector_steps=1,
+                   probability_flow: bool = False, intermediate=False, noise: Optional[torch.Tensor] = None,
+                   seed: Optional[int] = None, use_graph: bool = True, force_python_loop: bool = False, **kwargs):
+    """Predictor-corrector sampler (reference sampling/__init__.py:26-70).
+
+    Extra keyword arguments of this implementation: ``noise`` (complex64 [ndraws,B,1,F,T] replayed standard-normal
+    draws in the reference's call order, for bit-comparable runs), ``seed`` (Philox seed when ``noise`` is None;
+    default: drawn from torch's global RNG), ``use_graph``, ``force_python_loop``."""
+    predictor_cls = PredictorRegistry.get_by_name(predictor_name)   # ValueError for unknown names, like the reference
+    corrector_cls = CorrectorRegistry.get_by_name(corrector_name)
+
+    native = (not force_python_loop and predictor_name in _NATIVE_PRED and corrector_name in _NATIVE_CORR
+              and isinstance(sde, OUVESDE) and not intermediate)
+    ctx = _native_engine(score_fn, y) if native else None
+
+    if ctx is not None:
+        table = sde.step_table(eps, snr, sde.N)
+        std1 = float(sde._std(torch.ones(1))[0])
+        # like the reference's Predictor (predictors.py:18) the PC sampler ignores probability_flow
+        def native_pc_sampler():
+            s = seed if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+            with torch.no_grad():
+                out, nfe = ctx.pc_sample(y, table, theta=float(sde.theta), std1=std1, corrector=corrector_name,
+                                         corrector_steps=corrector_steps, predictor=predictor_name,
+                                         probability_flow=False, denoise=denoise, noise=noise, seed=s, use_graph=use_graph)
+            return out, nfe
+        return native_pc_sampler
+
+    predictor = predictor_cls(sde, score_fn, probability_flow=probability_flow)
+    corrector = corrector_cls(sde, score_fn, snr=snr, n_steps=corrector_steps)
+
+    def pc_sampler():
+        with torch.no_grad():
+            xt = sde.prior_sampling(y.shape, y).to(y.device)
+            timesteps = torch.linspace(sde.T, eps, sde.N, device=y.device)
+            xt_mean = xt
+            for i in range(sde.N):
+                t = timesteps[i]
+                stepsize = t - timesteps[i + 1] if i != len(timesteps) - 1 else timesteps[-1]
+                vec_t = torch.ones(y.shape[0], device=y.device) * t
+                xt, xt_mean = corrector.update_fn(xt, y, vec_t)
+                xt, xt_mean = predictor.update_fn(xt, y, vec_t, stepsize)
+            x_result = xt_mean if denoise else xt
+            ns = sde.N * (corrector.n_steps + 1)
+            return x_result, ns
+
+    return pc_sampler
+
+
+def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e-5, atol=1e-5, method="RK45", eps=3e-2,
+                    device=None, noise: Optional[torch.Tensor] = None, seed: Optional[int] = None, use_graph: bool = True,
+                    **kwargs):
+    """Corrector-free probability-flow sampler.
+
+    The reference's ``get_ode_sampler`` (sampling/__init__.py:73-143) is an adaptive scipy RK45 that round-trips every
+    evaluation through host NumPy and raises TypeError with its default ``denoise=True``.  This
+    implementation is the fixed-step counterpart on the sampler's own time grid: N Euler steps of
+    ``sde.reverse(score_fn, probability_flow=True).discretize`` (sdes.py:130-135), x <- x - rev_f, no noise, N NFE,
+    as one HIP loop.  ``rtol/atol/method/inverse_scaler/device`` are accepted and ignored."""
+    ctx = _native_engine(score_fn, y) if isinstance(sde, OUVESDE) else None
+    if ctx is None:
+        rsde = sde.reverse(score_fn, probability_flow=True)
+
+        def ode_sampler_py(z=None, **kw):
+            with torch.no_grad():
+                x = sde.prior_sampling(y.shape, y).to(y.device) if z is None else z
+                ts = torch.linspace(sde.T, eps, sde.N, device=y.device)
+                for i in range(sde.N):
+                    dt = ts[i] - ts[i + 1] if i != sde.N - 1 else ts[-1]
+                    f, _ = rsde.discretize(x, y, torch.ones(y.shape[0], device=y.device) * ts[i], dt)
+                    x = x - f
+                return x, sde.N
+        return ode_sampler_py
+
+    table = sde.step_table(eps, 0.0, sde.N)
+    std1 = float(sde._std(torch.ones(1))[0])
+
+    def ode_sampler(z=None, **kw):
+        s = seed if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+        with torch.no_grad():
+            return ctx.pc_sample(y, table, theta=float(sde.theta), std1=std1, corrector="none", corrector_steps=1,
+                                 predictor="reverse_diffusion", probability_flow=True, denoise=False, noise=noise, seed=s,
+                                 use_graph=use_graph)
+    return ode_sampler
+
+
+def get_sampler(sampler_type, *args, **kwargs):
+    if sampler_type == "pc":
+        return get_pc_sampler(*args, **kwargs)
+    if sampler_type == "ode":
+        return get_ode_sampler(*args, **kwargs)
+    raise ValueError(f"Given sampler type {sampler_type} not supported (the Schroedinger-bridge sampler is out of scope).")

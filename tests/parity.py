@@ -1,0 +1,210 @@
+"""Parity checks shared by the CPU (emulator) and GPU (HIP) test modules: every function runs one piece of the
+sgmse_amd path on ``dev`` and compares it with the oracle (oracle/, CPU torch fp32) or the golden fixtures produced by
+the reference itself (tests/golden/, oracle/make_golden.py)."""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_l2
+from oracle import ncsnpp_oracle as NO
+from oracle import sde_oracle as SO
+from oracle import stft_oracle as FO
+from oracle import synth
+
+OP_TOL = 1e-5          # per-op relative L2 (SURVEY 8-d parity gate)
+NET_TOL = 2e-5         # one network evaluation vs the reference's own output
+SAMPLER_TOL = 1e-4     # sampler output vs the reference (contractive chain)
+WAVE_TOL = 1e-3        # enhanced waveform, the north-star tolerance
+
+
+def gen(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+def R(g, *s):
+    return torch.randn(*s, generator=g)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def check_conv(dev, B, Ci, Co, H, W, ks, direct=False, dual=0, xform=False):
+    from sgmse_amd import ops
+    g = gen(B * 1000 + Ci + Co + H + W)
+    x = R(g, B, Ci, H, W); w = R(g, Co, Ci, ks, ks) / math.sqrt(Ci * ks * ks); b = R(g, Co); r = R(g, B, Co, H, W)
+    sc = sh = None
+    xin = x
+    if xform:
+        sc, sh = R(g, B, Ci), R(g, B, Ci)
+        xin = x * sc[:, :, None, None] + sh[:, :, None, None]
+        xin = xin * torch.sigmoid(xin)
+    ref = (F.conv2d(xin, w, b, padding=ks // 2) + r) / math.sqrt(2.0)
+    x1, x2 = (x[:, :Ci - dual].contiguous(), x[:, Ci - dual:].contiguous()) if dual else (x, None)
+    mv = lambda t: None if t is None else t.to(dev)
+    out = ops.conv2d(mv(x1), mv(w), mv(b), residual=mv(r), out_scale=1 / math.sqrt(2.0), x2=mv(x2), in_scale=mv(sc), in_shift=mv(sh),
+                     in_act=xform, force_direct=direct)
+    assert rel_l2(out.cpu(), ref) < OP_TOL, (B, Ci, Co, H, W, ks, direct, dual, xform)
+
+
+def check_groupnorm(dev, B, C, H, W, act=True, dual=0):
+    from sgmse_amd import ops
+    g = gen(C + H)
+    x = R(g, B, C, H, W) * 2 + 0.5; gw = R(g, C); gb = R(g, C)
+    ref = NO.group_norm(x, gw, gb)
+    if act:
+        ref = NO.silu(ref)
+    x1, x2 = (x[:, :C - dual].contiguous(), x[:, C - dual:].contiguous()) if dual else (x, None)
+    out = ops.group_norm(x1.to(dev), gw.to(dev), gb.to(dev), act=act, x2=None if x2 is None else x2.to(dev))
+    assert rel_l2(out.cpu(), ref) < OP_TOL
+
+
+def check_fir(dev, B=2, C=3, H=12, W=20):
+    from sgmse_amd import ops
+    x = R(gen(5), B, C, H, W)
+    if H >= 2 and W >= 2:
+        assert rel_l2(ops.fir_resample(x.to(dev), False).cpu(), NO.fir_down2(x)) < 1e-6
+    assert rel_l2(ops.fir_resample(x.to(dev), True).cpu(), NO.fir_up2(x)) < 1e-6
+
+
+def check_fir_golden(dev):
+    """Against the reference's own upfirdn2d_native outputs (fixture fir.npz)."""
+    from sgmse_amd import ops
+    z = load("fir")
+    x = torch.from_numpy(z["x"]).to(dev)
+    assert rel_l2(ops.fir_resample(x, False).cpu(), z["down"]) < 1e-6
+    assert rel_l2(ops.fir_resample(x, True).cpu(), z["up"]) < 1e-6
+    k = torch.from_numpy(z["kern"]).to(dev)
+    assert rel_l2(ops.upfirdn2d(x, k, up=3, down=2, pad=(2, 1)).cpu(), z["generic"]) < 1e-6
+    k4 = torch.outer(torch.tensor([1., 3, 3, 1]), torch.tensor([1., 3, 3, 1]))
+    k4 = (k4 / k4.sum()).to(dev)
+    assert rel_l2(ops.upfirdn2d(x, k4, down=2, pad=(1, 1)).cpu(), z["down"]) < 1e-6
+    assert rel_l2(ops.upfirdn2d(x, k4 * 4, up=2, pad=(2, 1)).cpu(), z["up"]) < 1e-6
+
+
+def check_attention(dev, B, C, S):
+    from sgmse_amd import ops
+    qkv = R(gen(S), B, 3 * C, S)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    w = torch.softmax(torch.einsum("bcs,bcr->bsr", q, k) * C ** -0.5, -1)
+    ref = torch.einsum("bsr,bcr->bcs", w, v)
+    assert rel_l2(ops.attention(qkv.to(dev)).cpu(), ref) < OP_TOL
+
+
+NET_CASES = {
+    "fwd_nf32": NO.NetCfg.for_variant("ncsnpp", nf=32),
+    "fwd_48k_nf32": NO.NetCfg.for_variant("ncsnpp_48k", nf=32),
+    "fwd_nf128": NO.NetCfg.for_variant("ncsnpp"),
+}
+
+
+def make_backbone(cfg, dev, P=None):
+    from sgmse_amd.backbones import BackboneRegistry
+    P = synth.synth_params(cfg, seed=0) if P is None else P
+    net = BackboneRegistry.get_by_name(cfg.variant)(nf=cfg.nf, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks,
+                                                    attn_resolutions=cfg.attn_resolutions, image_size=cfg.image_size,
+                                                    progressive=cfg.progressive, progressive_input=cfg.progressive_input)
+    net.load_state_dict(P, strict=True)     # pins the reference state_dict name/shape contract
+    return net.to(dev), P
+
+
+def check_forward_golden(dev, name, batch=None):
+    """NCSNpp.forward against the output of the reference's own module (fixture)."""
+    cfg = NET_CASES[name]
+    z = load(name)
+    net, _ = make_backbone(cfg, dev)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    ref = torch.from_numpy(z["out"])
+    if batch is not None:
+        x, t, ref = x[:batch], t[:batch], ref[:batch]
+    out = net(x.to(dev), t.to(dev))
+    assert out.shape == ref.shape and out.dtype == torch.complex64
+    assert rel_l2(out.cpu(), ref) < NET_TOL, name
+
+
+def make_model(cfg, dev, P=None, **kw):
+    from sgmse_amd.model import ScoreModel
+    P = synth.synth_params(cfg, seed=0) if P is None else P
+    sde_kw = dict(theta=1.5, sigma_min=0.05, sigma_max=0.5)
+    sde_kw.update(kw)
+    m = ScoreModel(cfg.variant, "ouve", nf=cfg.nf, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks,
+                   attn_resolutions=cfg.attn_resolutions, image_size=cfg.image_size, progressive=cfg.progressive,
+                   progressive_input=cfg.progressive_input, **sde_kw)
+    m.dnn.load_state_dict(P, strict=True)
+    m.to(dev)
+    m.eval()
+    return m, P
+
+
+def replay_noise(shape, ndraws, seed=7):
+    rep = SO.NoiseReplay(seed)
+    like = torch.zeros(shape, dtype=torch.complex64)
+    return torch.stack([rep(like) for _ in range(ndraws)])
+
+
+def check_sampler_golden(dev, tag, batch=None, use_graph=True):
+    """get_pc_sampler(...)() with replayed noise against the reference's own sampler output (fixture).  Utterances in
+    a batch are independent on this path, so a batch prefix of the fixture is a valid smaller case."""
+    z = load(tag)
+    cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
+    m, _ = make_model(cfg, dev)
+    y = torch.from_numpy(z["y"])
+    ref = torch.from_numpy(z["out"])
+    if tag.startswith("pfode"):
+        N, ndraws = 6, 1
+        noise = replay_noise(y.shape, ndraws)
+        if batch is not None:
+            y, ref, noise = y[:batch], ref[:batch], noise[:, :batch]
+        sampler = m.get_ode_sampler(y.to(dev), N=N, noise=noise.contiguous().to(dev), use_graph=use_graph)
+        out, nfe = sampler()
+        assert nfe == N
+    else:
+        N, corr = int(z["N"]), str(z["corrector"])
+        ndraws = 1 + N * (2 if corr != "none" else 1)
+        noise = replay_noise(y.shape, ndraws)
+        if batch is not None:
+            y, ref, noise = y[:batch], ref[:batch], noise[:, :batch]
+        sampler = m.get_pc_sampler(str(z["predictor"]), corr, y.to(dev), N=N, snr=float(z["snr"]),
+                                   noise=noise.contiguous().to(dev), use_graph=use_graph)
+        out, nfe = sampler()
+        assert nfe == int(z["nfe"])
+    assert rel_l2(out.cpu(), ref) < SAMPLER_TOL, tag
+
+
+def check_front_end(dev, fc, L):
+    from sgmse_amd.data_module import SpecsDataModule
+    dm = SpecsDataModule(n_fft=fc.n_fft, hop_length=fc.hop_length, spec_factor=fc.spec_factor,
+                         spec_abs_exponent=fc.spec_abs_exponent, window=fc.window, transform_type=fc.transform_type)
+    sig = synth.synth_waveform(L, seed=2, batch=2)
+    S_ref = FO.stft(sig, fc)
+    S = dm.stft(sig.to(dev))
+    assert S.shape == S_ref.shape and rel_l2(S.cpu(), S_ref) < 5e-6
+    assert rel_l2(dm.spec_fwd(S_ref.to(dev)).cpu(), FO.spec_fwd(S_ref, fc)) < 5e-6
+    Yf = FO.spec_fwd(S_ref, fc)
+    assert rel_l2(dm.spec_back(Yf.to(dev)).cpu(), FO.spec_back(Yf, fc)) < 5e-6
+    assert rel_l2(dm.istft(S_ref.to(dev), L).cpu(), FO.istft(S_ref, fc, L)) < 5e-6
+    # round trip (size-independent property): istft(stft(x)) == x
+    assert rel_l2(dm.istft(dm.stft(sig.to(dev)), L).cpu(), sig) < 1e-5
+    # padded spectrogram, shorter length: the tail envelope quirk of SURVEY Appendix C
+    Yp = FO.pad_spec(S_ref[None, :1], "zero_pad")[0]
+    assert rel_l2(dm.istft(Yp.to(dev), L).cpu(), FO.istft(Yp, fc, L)) < 5e-6
+
+
+def check_enhance(dev, L=8000, N=2):
+    """enhancement.py:62-99 end to end (normalise -> STFT -> sampler -> iSTFT -> renormalise) with replayed noise against
+    the oracle pipeline; the north-star gate: relative L2 <= 1e-3 on the enhanced waveform."""
+    cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
+    m, P = make_model(cfg, dev)
+    fc = FO.FrontCfg()
+    y = synth.synth_waveform(L, seed=0, batch=1)
+    sde = SO.OUVE(1.5, 0.05, 0.5, N)
+    rep = SO.NoiseReplay(7)
+    x_ref = FO.enhance(y, fc, lambda Y: SO.pc_sample(sde, lambda a, b, c: NO.score_fn(P, cfg, a, b, c), Y, rep, eps=0.03, snr=0.5)[0])
+    noise = torch.stack(rep.draws).to(dev)
+    x_hat = m.enhance(y, N=N, noise=noise)
+    assert rel_l2(x_hat, x_ref) < WAVE_TOL
+    xb, nfe = m.enhance_batch(y, N=N, noise=noise)
+    assert nfe == 2 * N and rel_l2(xb[0].cpu(), x_ref) < WAVE_TOL

@@ -1,0 +1,86 @@
+"""Kernel-logic parity on the CPU workgroup emulator (no GPU needed): the SAME kernel sources that hipcc builds for
+gfx950, compiled with g++ against tests/emu/sgmse_devrt.h, against the oracle and the reference-made fixtures.
+The `-m gpu` tests (test_gpu_parity.py) repeat these checks -- and larger ones -- through the real HIP library."""
+import os
+
+import pytest
+import torch
+
+import parity as P
+from oracle import stft_oracle as FO
+
+SLOW = os.environ.get("SGMSE_SLOW", "0") == "1"
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 32, 32, 16, 40, 3), (1, 64, 128, 9, 33, 3), (2, 32, 64, 4, 8, 3), (1, 96, 32, 8, 32, 1), (2, 64, 64, 5, 7, 1),
+    (1, 64, 64, 3, 1, 3), (1, 32, 32, 1, 1, 1)])
+def test_conv_mfma(emu, shape):
+    P.check_conv(emu, *shape)
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 32, 10, 12, 3), (2, 32, 4, 10, 12, 3), (1, 4, 32, 6, 5, 1), (1, 24, 20, 7, 9, 3)])
+def test_conv_direct(emu, shape):
+    P.check_conv(emu, *shape, direct=True)
+
+
+def test_conv_concat_and_fused_groupnorm_silu(emu):
+    P.check_conv(emu, 2, 96, 32, 12, 36, 3, dual=64, xform=True)
+    P.check_conv(emu, 1, 64, 32, 8, 8, 1, dual=32, xform=True)
+    P.check_conv(emu, 1, 12, 4, 6, 6, 3, direct=True, dual=4, xform=True)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 8, 8), (1, 96, 5, 7), (2, 128, 16, 16)])
+def test_groupnorm(emu, shape):
+    P.check_groupnorm(emu, *shape)
+    P.check_groupnorm(emu, *shape, act=False)
+
+
+def test_groupnorm_concat_group_straddles_sources(emu):
+    P.check_groupnorm(emu, 2, 96, 6, 10, dual=32)     # 24 groups of 4: boundary at channel 64 is aligned
+    P.check_groupnorm(emu, 1, 384, 4, 4, dual=128)    # 32 groups of 12: group 21 straddles channel 256
+
+
+def test_fir(emu):
+    P.check_fir(emu)
+    P.check_fir(emu, 1, 2, 4, 1)
+    P.check_fir_golden(emu)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 40), (1, 32, 4), (1, 256, 100), (1, 64, 160)])
+def test_attention(emu, shape):
+    P.check_attention(emu, *shape)
+
+
+def test_forward_matches_reference_ncsnpp(emu):
+    P.check_forward_golden(emu, "fwd_nf32", batch=1)
+
+
+def test_forward_matches_reference_ncsnpp_48k(emu):
+    P.check_forward_golden(emu, "fwd_48k_nf32")
+
+
+@pytest.mark.skipif(not SLOW, reason="full-width network on the emulator takes minutes; SGMSE_SLOW=1")
+@pytest.mark.slow
+def test_forward_matches_reference_full_width(emu):
+    P.check_forward_golden(emu, "fwd_nf128")
+
+
+def test_pc_sampler_matches_reference(emu):
+    P.check_sampler_golden(emu, "pc_N4", batch=1)
+
+
+@pytest.mark.skipif(not SLOW, reason="SGMSE_SLOW=1")
+@pytest.mark.slow
+@pytest.mark.parametrize("tag", ["pnone_N6", "pfode_N6"])
+def test_corrector_free_samplers_match_reference(emu, tag):
+    P.check_sampler_golden(emu, tag, batch=1)
+
+
+@pytest.mark.parametrize("fc,L", [(FO.FrontCfg(), 4000), (FO.FrontCfg.ears_48k(), 9000)])
+def test_front_end(emu, fc, L):
+    P.check_front_end(emu, fc, L)
+
+
+def test_enhance_end_to_end(emu):
+    P.check_enhance(emu, L=8000, N=1)
