@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterances/s (and RTF) of the reverse-SDE enhancement path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic 16 kHz utterances already resident in HBM:
+STFT -> spec_fwd -> pad -> PC sampler (reverse_diffusion + ALD, N=30, snr=0.5 => 60 NCSN++ evaluations, captured as a
+hipGraph step replayed N times) -> spec_back -> iSTFT.  Workload = BASELINE.json configs[1] (batch 32, 4 s utterances,
+full 65.6 M-parameter NCSN++, fp32, random-init weights).  N > 1: one process per GPU (torch.distributed, RCCL), every
+rank enhances its own batch (weak scaling), the only collective is one weight broadcast before the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     dominant kernel = conv3x3 fp32 MFMA implicit GEMM (128-channel x 256-pixel tile); achieved = algorithmic
+               FLOPs of its launches / their HIP-event time, measured by one instrumented (eager) network evaluation on
+               the same batch right after the timed region; peak = 157.3 TFLOP/s fp32 (MI355X_MICROARCH.md)
+  cpu_baseline the CPU oracle (oracle/, a torch-fp32 restatement of the reference) timed on this box's host cores on
+               a bounded sample, extrapolated to the 60-evaluation run
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_EVAL = 1.064686e12       # algorithmic FLOPs of one NCSN++ evaluation at [1,4,256,512]
+FP32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--sampler", choices=("pc", "ode"), default="pc")
+    ap.add_argument("--N", type=int, default=30)
+    ap.add_argument("--snr", type=float, default=0.5)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-evals", type=int, default=2, help="timed CPU score evaluations for the baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(state, n_evals, N, snr):
+    """Oracle (port of the reference's CPU path) on the host cores: B=1, 4 s utterance; bounded sample, extrapolated."""
+    import torch
+    from oracle import ncsnpp_oracle as NO, sde_oracle as SO, stft_oracle as FO
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = NO.NetCfg.for_variant("ncsnpp")
+    P = {k: v.detach().cpu().float() for k, v in state.items()}
+    fc = FO.FrontCfg()
+    g = torch.Generator().manual_seed(0)
+    y = torch.randn(1, 64000, generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        Y = FO.pad_spec(FO.spec_fwd(FO.stft(y / y.abs().max(), fc), fc)[None], "zero_pad")
+        sde = SO.OUVE(1.5, 0.05, 0.5, N)
+        rep = SO.NoiseReplay(7)
+        x = sde.prior(Y, rep)
+        t_front = time.perf_counter() - t0
+        tvec = torch.ones(1)
+        NO.score_fn(P, cfg, x, Y, tvec)                       # warm-up (thread pools, oneDNN primitives)
+        t0 = time.perf_counter()
+        for _ in range(n_evals):
+            s = NO.score_fn(P, cfg, x, Y, tvec)
+        t_eval = (time.perf_counter() - t0) / n_evals
+        t0 = time.perf_counter()
+        x2, _ = SO.ald_update(sde, lambda a, b, c: s, x, Y, tvec, snr, rep)
+        x3, xm = SO.revdiff_update(sde, lambda a, b, c: s, x2, Y, tvec, torch.tensor(1.0 / N), rep)
+        t_glue = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        FO.istft(FO.spec_back(xm[0, 0], fc), fc, 64000)
+        t_back = time.perf_counter() - t0
+    per_utt = t_front + t_back + 2 * N * t_eval + N * t_glue
+    return {"value": 1.0 / per_utt, "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": f"{n_evals} timed NCSN++ evaluations at [1,4,256,512] after 1 warm-up ({t_eval:.2f} s each) + front-end "
+                      f"+ one PC step of sampler glue, extrapolated to {2 * N} evaluations; B=1, 4 s utterance",
+            "seconds_per_eval": t_eval, "rtf": per_utt / 4.0}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from sgmse_amd import _lib
+    from sgmse_amd.model import ScoreModel
+    from sgmse_amd.parallel import broadcast_backbone_weights
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: sgmse_amd has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    _lib.load_library()
+
+    L = int(a.seconds * 16000)
+    torch.manual_seed(0)
+    model = ScoreModel("ncsnpp", "ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, N=a.N)   # 65.6 M params, random init
+    model.to(dev).eval()
+    bcast_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        broadcast_backbone_weights(model.dnn, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+
+    g = torch.Generator().manual_seed(1000 + rank)
+    y = torch.randn(a.batch, L, generator=g).to(dev)          # resident in HBM before the timed region
+
+    def step(i):
+        x_hat, nfe = model.enhance_batch(y, N=a.N, snr=a.snr, sampler_type=a.sampler, seed=17 + i, use_graph=not a.no_graph)
+        return x_hat, nfe
+
+    def fence():
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    nfe = 0
+    for i in range(a.warmup):
+        _, nfe = step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        x_hat, nfe = step(a.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(x_hat).all()
+
+    out = None
+    if rank == 0:
+        utts = world * a.batch * a.steps
+        T = ((L // 128 + 1) + 63) // 64 * 64
+        flop_eval = FLOP_PER_EVAL * (T / 512.0)
+        out = {
+            "metric": "utterances/sec, SGMSE+ NCSN++ PC N=30 (reverse_diffusion + ALD, 60 NFE), 16 kHz 4 s utterances",
+            "value": utts / elapsed, "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (N(0,1) waveforms, random-init weights of the full architecture)",
+            "config": {"workload": f"BASELINE configs[1]: NCSN++ (65.6M params) {a.sampler.upper()} sampler N={a.N}, "
+                                   f"batch={a.batch} x {a.seconds:g} s @16 kHz per GPU, hipGraph-captured step",
+                       "batch_per_gpu": a.batch, "F": 256, "T": T, "nfe": nfe, "sampler": a.sampler, "snr": a.snr,
+                       "parallelism": f"utterance-sharded x{world} (weights broadcast once over RCCL)"},
+            "rtf": elapsed / (utts * a.seconds),
+            "path_tflops": a.batch * a.steps * nfe * flop_eval / elapsed / 1e12,
+            "path_frac_of_fp32_peak": a.batch * a.steps * nfe * flop_eval / elapsed / 1e12 / FP32_PEAK_TFLOPS,
+        }
+        if bcast_ms is not None:
+            out["weight_broadcast_ms"] = bcast_ms
+        if not a.no_profile:
+            Y = torch.randn(a.batch, 2, 256, T, dtype=torch.complex64, device=dev) * 0.3
+            tt = torch.full((a.batch,), 0.5, device=dev)
+            ctx = model.dnn.engine(dev)
+            prof, _ = ctx.profile_forward(Y, tt)
+            dom = prof["conv3x3_mfma_128x256"]
+            ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "conv_mfma_kernel<3,2,2,4,*> (3x3 fp32 implicit GEMM, 128co x 256px tile)",
+                               "launches_per_eval": dom["launches"],
+                               "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),
+                               "flop_per_launch_avg": dom["work"] / max(dom["launches"], 1)}
+            classes = {}
+            for k, v in prof.items():
+                rate = v["work"] / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
+                classes[k] = {"ms": round(v["ms"], 3), "launches": v["launches"],
+                              ("tflops" if v["unit"] == "flop" else "gbps"): rate / (1e12 if v["unit"] == "flop" else 1e9)}
+            out["kernel_classes_one_eval"] = classes
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model.dnn.state_dict(), a.cpu_evals, a.N, a.snr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -267,10 +267,25 @@ class Context:
                 raise ValueError(f"noise must be [{need},{B},1,{F_},{T}] complex64, got {tuple(noise.shape)}")
         out = torch.empty_like(Y)
         nfe = _I(0)
-        self.use_current_stream()
-        self.check(self.lib.sgmse_pc_sample(self.h, Y.data_ptr(), out.data_ptr(), B, F_, T, C.byref(cfg), ptr(noise),
-                                            C.c_ulonglong(seed & (2 ** 64 - 1)), C.byref(nfe)))
-        self._keep["sampler"] = (Y, noise, keep)   # the captured graph refers to these buffers
+
+        def run():
+            self.use_current_stream()
+            self.check(self.lib.sgmse_pc_sample(self.h, Y.data_ptr(), out.data_ptr(), B, F_, T, C.byref(cfg), ptr(noise),
+                                                C.c_ulonglong(seed & (2 ** 64 - 1)), C.byref(nfe)))
+
+        cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        if cur is not None and use_graph and cur.cuda_stream == 0:
+            # stream capture is not allowed on the legacy default stream: run the sampler on a side stream
+            side = self._keep.get("side_stream")
+            if side is None:
+                side = self._keep["side_stream"] = torch.cuda.Stream(self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                run()
+            cur.wait_stream(side)
+        else:
+            run()
+        self._keep["sampler"] = (noise, keep)   # the captured graph refers to the replayed-noise buffer
         return out, nfe.value
 
     def profile_forward(self, xy: torch.Tensor, t: torch.Tensor):

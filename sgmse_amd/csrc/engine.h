@@ -253,7 +253,7 @@ class Engine {
   }
 
   drt::stream_t stream() const { return stream_; }
-  void set_stream(void* s) { stream_ = reinterpret_cast<drt::stream_t>(s); invalidate_graph(); }
+  void set_stream(void* s) { stream_ = reinterpret_cast<drt::stream_t>(s); }  // a captured graph can be launched on any stream
 
   // ---- weights ----------------------------------------------------------------------------------------------
   void set_config(const NetCfg& c) { cfg_ = c; layout_ = build_layout(c); weights_ready_ = false; invalidate_graph(); }
@@ -331,6 +331,8 @@ class Engine {
     const bool pred_noise = sc.predictor == 1 && !sc.probability_flow;
     const int draws_per_step = ncorr + (pred_noise ? 1 : 0);
 
+    SG_CHECK(drt::memcpy_d2d(sy_, Y, n * 8, stream_));   // engine-owned copy: the captured graph never refers to caller memory
+    Y = sy_;
     SamplerArgs sa{};
     sa.x = sx_; sa.x_mean = sxm_; sa.y = Y; sa.score = sscore_; sa.noise = noise; sa.seed = seed;
     sa.table = step_table_; sa.step_ptr = step_ctr_; sa.theta = sc.theta; sa.std1 = sc.std1; sa.n = (int)n;
@@ -629,7 +631,7 @@ class Engine {
       arena_.configure(arena_base_, arena_cap_);
       const size_t n = (size_t)B * F * T;
       if (n > samp_n_) {
-        for (float2** q : {&sx_, &sxm_, &sscore_}) { if (*q) dev_free_owned(*q); *q = static_cast<float2*>(dev_alloc(n * 8)); }
+        for (float2** q : {&sx_, &sxm_, &sscore_, &sy_}) { if (*q) dev_free_owned(*q); *q = static_cast<float2*>(dev_alloc(n * 8)); }
         samp_n_ = n;
       }
       if (!step_ctr_) step_ctr_ = static_cast<int*>(dev_alloc(256));
@@ -925,7 +927,7 @@ class Engine {
   Arena arena_; char* arena_base_ = nullptr; size_t arena_cap_ = 0;
   bool dry_ = false;
   int B_ = 0, shape_B_ = 0, shape_F_ = 0, shape_T_ = 0;
-  float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr; size_t samp_n_ = 0;
+  float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr, *sy_ = nullptr; size_t samp_n_ = 0;
   int* step_ctr_ = nullptr;
   float *temb_act_ = nullptr, *bias_table_ = nullptr, *step_table_ = nullptr, *tsteps_ = nullptr; int temb_rows_ = 0;
   drt::graph_t graph_{}; bool graph_valid_ = false; GraphKey graph_key_{};
