@@ -1,0 +1,248 @@
+"""Host-side logic and the C-ABI surface, CPU only (no compute on a GPU): registries, pad_spec, state-dict contract,
+Lightning-checkpoint ingestion with the EMA swap, exported symbols, error behaviour, sharding arithmetic."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import HIP_LIB, ROOT, rel_l2
+
+
+def test_registries_match_reference_names():
+    from sgmse_amd.backbones import BackboneRegistry
+    from sgmse_amd.sdes import SDERegistry
+    from sgmse_amd.sampling import PredictorRegistry, CorrectorRegistry
+    assert set(BackboneRegistry.get_all_names()) >= {"ncsnpp", "ncsnpp_48k"}
+    assert "ouve" in SDERegistry.get_all_names()
+    assert set(PredictorRegistry.get_all_names()) == {"euler_maruyama", "reverse_diffusion", "none"}
+    assert set(CorrectorRegistry.get_all_names()) == {"langevin", "ald", "none"}
+    for reg in (BackboneRegistry, SDERegistry, PredictorRegistry, CorrectorRegistry):
+        with pytest.raises(ValueError):
+            reg.get_by_name("no-such-thing")
+
+
+def test_pad_spec():
+    from sgmse_amd.util.other import pad_spec
+    from oracle import stft_oracle as FO
+    Y = torch.randn(2, 1, 8, 501, dtype=torch.complex64)
+    for mode in ("zero_pad", "reflection", "replication"):
+        out = pad_spec(Y, mode)
+        assert out.shape[-1] == 512 and torch.equal(out, FO.pad_spec(Y, mode))
+    assert pad_spec(Y[..., :448]).shape[-1] == 448
+    with pytest.raises(NotImplementedError):
+        pad_spec(Y, "circular")
+
+
+def test_state_dict_contract_full_width():
+    """647 tensors / 65,590,822 parameters, output_layer first; 48 kHz variant 64,739,854."""
+    from sgmse_amd.backbones import BackboneRegistry
+    from oracle import ncsnpp_oracle as NO
+    net = BackboneRegistry.get_by_name("ncsnpp")()
+    sd = net.state_dict()
+    want = NO.param_shapes(NO.NetCfg.for_variant("ncsnpp"))
+    assert list(sd.keys()) == list(want.keys())
+    assert all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
+    assert sum(v.numel() for v in sd.values()) == 65_590_822
+    assert [k for k, p in net.named_parameters() if not p.requires_grad] == ["all_modules.0.W"]
+    net48 = BackboneRegistry.get_by_name("ncsnpp_48k")()
+    assert sum(v.numel() for v in net48.state_dict().values()) == 64_739_854
+    with pytest.raises(NotImplementedError):
+        BackboneRegistry.get_by_name("ncsnpp")(resblock_type="ddpm")
+
+
+def test_ouve_matches_oracle_scalars():
+    from sgmse_amd.sdes import OUVESDE
+    from oracle import sde_oracle as SO
+    for (th, a, b, N, snr) in ((1.5, 0.05, 0.5, 30, 0.5), (2.0, 0.1, 1.0, 50, 0.33)):
+        tab = OUVESDE(th, a, b, N=N).step_table(0.03, snr)
+        ref = SO.step_table(SO.OUVE(th, a, b, N), 0.03, snr)
+        for k in ref:
+            assert torch.equal(tab[k], ref[k]), k
+    s = OUVESDE(1.5, 0.05, 0.5, N=30)
+    c = s.copy()
+    assert (c.theta, c.sigma_min, c.sigma_max, c.N, c.sampler_type) == (1.5, 0.05, 0.5, 30, "pc") and s.T == 1
+
+
+def test_generic_python_sampler_matches_oracle_with_fake_score():
+    """The registry predictor/corrector classes (Python loop) against the oracle with an analytic score."""
+    from sgmse_amd import sampling
+    from sgmse_amd.sdes import OUVESDE
+    from oracle import sde_oracle as SO
+    y = torch.randn(2, 1, 8, 16, dtype=torch.complex64, generator=torch.Generator().manual_seed(0))
+    score = lambda x, yy, t: (yy - x) * 0.7
+    for pred, corr in (("reverse_diffusion", "ald"), ("reverse_diffusion", "langevin"), ("reverse_diffusion", "none")):
+        rep = SO.NoiseReplay(3)
+        ref, nfe_ref = SO.pc_sample(SO.OUVE(1.5, 0.05, 0.5, 5), score, y, rep, eps=0.03, snr=0.5, corrector=corr, predictor=pred)
+        rep2 = SO.NoiseReplay(3)
+        orig = torch.randn_like
+        torch.randn_like = lambda like, **kw: rep2(like)
+        try:
+            out, nfe = sampling.get_pc_sampler(pred, corr, OUVESDE(1.5, 0.05, 0.5, N=5), score, y, eps=0.03, snr=0.5)()
+        finally:
+            torch.randn_like = orig
+        assert nfe == nfe_ref and rel_l2(out, ref) < 1e-6, (pred, corr)
+
+
+def test_checkpoint_ingestion_and_ema_swap(tmp_path):
+    """Lightning .ckpt layout: state_dict with 'dnn.' prefix, hyper_parameters incl. the pickled
+    data-module class, 'ema' shadow parameters used by eval() and restored by train()."""
+    from sgmse_amd.model import ScoreModel
+    from sgmse_amd.data_module import SpecsDataModule
+    hp = dict(backbone="ncsnpp", sde="ouve", nf=32, theta=1.5, sigma_min=0.05, sigma_max=0.5, N=30, t_eps=0.03,
+              data_module_cls=SpecsDataModule, n_fft=510, hop_length=128, spec_factor=0.15, spec_abs_exponent=0.5,
+              no_wandb=True)
+    src = ScoreModel(**{k: v for k, v in hp.items() if k != "no_wandb"})
+    sd = {"dnn." + k: v.clone() for k, v in src.dnn.state_dict().items()}
+    shadow = [p.detach() * 2 + 1 for p in src.dnn.parameters() if p.requires_grad]     # torch_ema tracks trainable params
+    path = tmp_path / "m.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": hp, "ema": {"decay": 0.999, "num_updates": 1,
+                                                                     "shadow_params": shadow, "collected_params": None}}, path)
+    m = ScoreModel.load_from_checkpoint(str(path), map_location="cpu")
+    assert m.backbone == "ncsnpp" and m.sde.__class__.__name__ == "OUVESDE" and m.t_eps == 0.03 and m.sr == 16000
+    raw = [p.detach().clone() for p in m.dnn.parameters() if p.requires_grad]
+    m.eval()
+    assert all(torch.equal(p, s) for p, s in zip([q for q in m.dnn.parameters() if q.requires_grad], shadow))
+    m.train(True)
+    assert all(torch.equal(p, r) for p, r in zip([q for q in m.dnn.parameters() if q.requires_grad], raw))
+    m.eval(no_ema=True)
+    assert all(torch.equal(p, r) for p, r in zip([q for q in m.dnn.parameters() if q.requires_grad], raw))
+    with pytest.warns(UserWarning):
+        torch.save({"state_dict": sd, "hyper_parameters": hp}, path)
+        ScoreModel.load_from_checkpoint(str(path))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libsgmse_hip.so loads without a GPU and exports exactly what include/sgmse_hip.h declares."""
+    assert os.path.exists(HIP_LIB), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    hdr = open(os.path.join(ROOT, "include", "sgmse_hip.h")).read()
+    declared = set(re.findall(r"\b(sgmse_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(HIP_LIB)
+    for name in declared:
+        assert hasattr(lib, name), name
+    from sgmse_amd import _lib
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    lib.sgmse_backend.restype = ctypes.c_char_p
+    assert lib.sgmse_backend() == b"hip-gfx950"
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU / PyTorch fallback: with the HIP library loaded and no GPU visible, creating a context raises."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch\nfrom sgmse_amd import _lib\n_lib.load_library()\n"
+            "try:\n    _lib.Context('cuda')\nexcept _lib.SgmseLibraryError as e:\n    print('RAISED', e)\n"
+            "try:\n    _lib.Context('cpu')\nexcept _lib.SgmseLibraryError as e:\n    print('RAISED2', e)\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "RAISED " in out.stdout and "RAISED2" in out.stdout, out.stdout + out.stderr
+
+
+def test_error_codes_and_messages(emu):
+    from sgmse_amd import _lib, ops
+    ctx = _lib.Context("cpu")
+    with pytest.raises(ValueError):
+        ctx.configure(variant="dcunet", nf=32, ch_mult=(1,), num_res_blocks=1, attn_resolutions=(), image_size=256,
+                      progressive="none", progressive_input="none")
+    with pytest.raises(ValueError):
+        ctx.configure(variant="ncsnpp", nf=33, ch_mult=(1,), num_res_blocks=1, attn_resolutions=(), image_size=256,
+                      progressive="none", progressive_input="none")
+    ctx.configure(variant="ncsnpp", nf=32, ch_mult=(1, 1), num_res_blocks=1, attn_resolutions=(), image_size=256,
+                  progressive="none", progressive_input="none")
+    with pytest.raises(RuntimeError, match="weights not loaded"):
+        ctx.forward(torch.zeros(1, 2, 4, 4, dtype=torch.complex64), torch.ones(1))
+    with pytest.raises(RuntimeError, match="missing parameter"):
+        ctx.load_weights({"output_layer.weight": torch.zeros(2, 4, 1, 1)})
+    with pytest.raises(ValueError):
+        ops.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 5, 5))
+    with pytest.raises(ValueError):
+        ops.conv2d(torch.zeros(1, 8, 4, 4, dtype=torch.float64), torch.zeros(8, 8, 3, 3))
+    with pytest.raises(RuntimeError, match="length"):
+        ops.istft(torch.zeros(1, 256, 4, dtype=torch.complex64), 510, 128, torch.hann_window(510), length=10000)
+    with pytest.raises(NotImplementedError):
+        ops.spec_transform(torch.zeros(4, dtype=torch.complex64), "mel", 1.0, 1.0, False)
+
+
+def test_shard_range():
+    from sgmse_amd.parallel import shard_range
+    for n, w in ((256, 8), (10, 4), (3, 8), (7, 1)):
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert all(b - a == n // w for a, b in spans[:-1])
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from sgmse_amd import _lib
+_lib.load_library({emu!r})
+from sgmse_amd.model import ScoreModel
+from sgmse_amd.parallel import shard_range, broadcast_backbone_weights
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+torch.manual_seed(100 + rank)                       # ranks start from DIFFERENT weights; rank 0's must win
+m = ScoreModel('ncsnpp', 'ouve', nf=32, theta=1.5, sigma_min=0.05, sigma_max=0.5)
+if rank != 0:
+    with torch.no_grad():
+        for p in m.dnn.parameters(): p.add_(1.0)
+m.eval()
+broadcast_backbone_weights(m.dnn, src=0)
+g = torch.Generator().manual_seed(5)
+wav = torch.randn(2, 8000, generator=g)              # the whole 2-utterance "file list"
+a, b = shard_range(2, rank, world)
+out, nfe = m.enhance_batch(wav[a:b], N=1, corrector='none', seed=11 + a)
+gathered = [torch.zeros(1, 8000) for _ in range(world)]
+dist.all_gather(gathered, out.contiguous())
+if rank == 0:
+    torch.save(torch.cat(gathered), {out!r})
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_rank_utterance_sharding_gloo(emu, tmp_path):
+    """World size 2 on CPU (gloo): weights broadcast from rank 0, utterances sharded contiguously, no collective on the
+    data path; the gathered result equals a single-process run."""
+    from conftest import EMU_LIB
+    out = str(tmp_path / "gathered.pt")
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, emu=EMU_LIB, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2", SGMSE_EMU_THREADS="4")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    got = torch.load(out)
+    from sgmse_amd.model import ScoreModel
+    torch.manual_seed(100)
+    m = ScoreModel("ncsnpp", "ouve", nf=32, theta=1.5, sigma_min=0.05, sigma_max=0.5)
+    m.eval()
+    wav = torch.randn(2, 8000, generator=torch.Generator().manual_seed(5))
+    ref = torch.cat([m.enhance_batch(wav[i:i + 1], N=1, corrector="none", seed=11 + i)[0] for i in range(2)])
+    assert torch.equal(got, ref)
+
+
+def test_reference_package_name_alias(tmp_path):
+    """`sgmse_amd/compat` on the path makes the reference's import lines (enhancement.py:15-16) and a checkpoint that
+    pickles `sgmse.data_module.SpecsDataModule` resolve to this implementation."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, pickle\n"
+            "from sgmse.model import ScoreModel\n"
+            "from sgmse.util.other import pad_spec, set_torch_cuda_arch_list\n"
+            "from sgmse.backbones.shared import BackboneRegistry\n"
+            "from sgmse.data_module import SpecsDataModule\n"
+            "import sgmse_amd.model\n"
+            "assert ScoreModel is sgmse_amd.model.ScoreModel\n"
+            "assert SpecsDataModule.__module__ == 'sgmse_amd.data_module'\n"
+            "blob = b'csgmse.data_module\\nSpecsDataModule\\n.'\n"     # what a Lightning ckpt's hyper_parameters contain
+            "assert pickle.loads(blob) is SpecsDataModule\n"
+            "set_torch_cuda_arch_list(); print('ALIAS-OK', BackboneRegistry.get_all_names())\n"
+            ) % (ROOT, os.path.join(ROOT, "sgmse_amd", "compat"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "ALIAS-OK" in out.stdout, out.stdout + out.stderr
