@@ -130,6 +130,11 @@ int sgmse_op_attention(sgmse_ctx* ctx, const float* qkv, float* out, int B, int 
 #define SGMSE_NCLASS 8
 int sgmse_profile_forward(sgmse_ctx* ctx, const void* xy, const float* t, void* out, int B, int F, int T, float* ms,
                           double* work, int* launches);
+/* micro-benchmark of one MFMA convolution shape on random operands: ms per launch over `iters` back-to-back launches
+ * (HIP events on the context's stream).  variant: kernel-variant id (see kernels_conv.h), -1 = default.
+ * fused = 1 adds the GroupNorm-affine+SiLU producer and the bias/residual/scale epilogue.  synchronises */
+int sgmse_bench_conv(sgmse_ctx* ctx, int ks, int B, int Cin, int Cout, int H, int W, int variant, int iters, int fused,
+                     float* ms);
 int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out);
 
 #ifdef __cplusplus

@@ -64,6 +64,7 @@ _SIGS = {
     "sgmse_op_fir": (_I, [_P, _P, _P, _I, _I, _I, _I]),
     "sgmse_op_attention": (_I, [_P, _P, _P, _I, _I, _I]),
     "sgmse_profile_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(_I)]),
+    "sgmse_bench_conv": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "sgmse_arena_bytes": (_I, [_P, C.POINTER(_LL)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
@@ -300,6 +301,12 @@ class Context:
         self.check(self.lib.sgmse_profile_forward(self.h, xy.data_ptr(), t.data_ptr(), out.data_ptr(), B, F_, T, ms, fl, nl))
         return {n: {"ms": ms[i], "work": fl[i], "unit": CLASS_WORK_UNIT[i], "launches": nl[i]}
                 for i, n in enumerate(CLASS_NAMES)}, out
+
+    def bench_conv(self, ks, B, Cin, Cout, H, W, variant=-1, iters=10, fused=False) -> float:
+        ms = _F(0)
+        self.use_current_stream()
+        self.check(self.lib.sgmse_bench_conv(self.h, ks, B, Cin, Cout, H, W, variant, iters, int(fused), C.byref(ms)))
+        return ms.value
 
     def arena_bytes(self) -> int:
         out = _LL(0)

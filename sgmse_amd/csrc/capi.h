@@ -170,6 +170,11 @@ int sgmse_profile_forward(sgmse_ctx* ctx, const void* xy, const float* t, void* 
   return sg_guard(ctx, [&](sgmse::Engine& e) { e.profile_forward((const float2*)xy, t, (float2*)out, B, F, T, ms, work, launches); });
 }
 
+int sgmse_bench_conv(sgmse_ctx* ctx, int ks, int B, int Cin, int Cout, int H, int W, int variant, int iters, int fused, float* ms) {
+  SG_ARG(ctx, ms && iters > 0 && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (ks == 1 || ks == 3), "bad arguments");
+  return sg_guard(ctx, [&](sgmse::Engine& e) { *ms = e.bench_conv(ks, B, Cin, Cout, H, W, variant, iters, fused); });
+}
+
 int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out) {
   SG_ARG(ctx, out != nullptr, "out is null");
   return sg_guard(ctx, [&](sgmse::Engine& e) { *out = (long long)e.arena_bytes(); });

@@ -158,6 +158,15 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs p) {
   p.dst[e] = v;
 }
 
+// deterministic pseudo-random fill in [-1, 1) (benchmark operands must not be zeros: DVFS, MI355X_MICROARCH.md)
+__global__ __launch_bounds__(256) void fill_random_kernel(float* dst, size_t n, uint32_t seed) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  dst[i] = (float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f;
+}
+
 // [cin][cout] -> [cout][cin]
 __global__ __launch_bounds__(256) void transpose_io_kernel(const float* src, float* dst, int cin, int cout) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -379,7 +388,7 @@ class Engine {
       for (int i = 0; i < sc.N; ++i) step_body();
     }
     SG_CHECK(drt::memcpy_d2d(out, sc.denoise ? sxm_ : sx_, n * 8, stream_));
-    nfe_ = sc.N * (ncorr + (sc.predictor == 1 ? 1 : 0));
+    nfe_ = sc.N * (ncorr + 1);   // the reference counts N*(corrector.n_steps+1) whatever the predictor (sampling/__init__.py:67)
   }
   int last_nfe() const { return nfe_; }
   size_t arena_bytes() const { return arena_cap_; }
@@ -472,6 +481,43 @@ class Engine {
   }
 
   void sync() { SG_CHECK(drt::stream_sync(stream_)); }
+
+  // Kernel micro-benchmark of one MFMA convolution shape on random operands: `iters` back-to-back launches between two
+  // events on this stream.  variant = SGMSE_CONV_VARIANT encoding (-1: process default).  Returns ms per launch.
+  float bench_conv(int ks, int B, int Cin, int Cout, int H, int W, int variant, int iters, int fused) {
+    ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
+    SG_REQUIRE(pl.mfma, "bench_conv: shape is not MFMA-eligible");
+    const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * Cout * H * W, nw = (size_t)Cout * Cin * ks * ks;
+    const size_t ne = packed_weight_elems(ks, Cin, Cout, pl.co_t);
+    float* x = static_cast<float*>(dev_alloc_tmp(nx * 4));
+    float* o = static_cast<float*>(dev_alloc_tmp(no * 4));
+    float* r = static_cast<float*>(dev_alloc_tmp(no * 4));
+    float* w = static_cast<float*>(dev_alloc_tmp(nw * 4));
+    float* pk = static_cast<float*>(dev_alloc_tmp(ne * 4));
+    float* sc = static_cast<float*>(dev_alloc_tmp((size_t)B * Cin * 8));
+    auto fill = [&](float* d, size_t n, uint32_t seed) {
+      DRT_LAUNCH(fill_random_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), stream_, d, n, seed);
+    };
+    fill(x, nx, 1); fill(r, no, 2); fill(w, nw, 3); fill(sc, (size_t)B * Cin * 2, 4);
+    PackArgs pa{}; pa.src[0] = w; pa.nsrc = 1; pa.cout_per_src = Cout; pa.io = 0; pa.cin = Cin; pa.taps = ks * ks; pa.cout = Cout;
+    pa.co_t = pl.co_t; pa.dst = pk; pa.total = ne;
+    DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, pa);
+    ConvArgs a{};
+    a.src1 = x; a.C1 = Cin; a.w = pk; a.out = o; a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.out_scale = 1.f;
+    if (fused) { a.in_scale = sc; a.in_shift = sc + (size_t)B * Cin; a.in_act = 1; a.res = r; a.bias = w; a.out_scale = 0.70710678f; }
+    drt::event_t e0{}, e1{};
+    drt::event_create(&e0); drt::event_create(&e1);
+    for (int i = 0; i < 2; ++i) launch_conv_mfma(a, ks, pl, stream_, variant);
+    drt::event_record(&e0, stream_);
+    for (int i = 0; i < iters; ++i) launch_conv_mfma(a, ks, pl, stream_, variant);
+    drt::event_record(&e1, stream_);
+    drt::event_sync(&e1);
+    const float ms = drt::event_elapsed_ms(e0, e1) / (float)iters;
+    check_launch();
+    drt::event_destroy(&e0); drt::event_destroy(&e1);
+    for (float* q : {x, o, r, w, pk, sc}) free_tmp(q);
+    return ms;
+  }
 
   // per-kernel-class timing of one forward (eager, events on this stream); fills ms per class
   enum { TC_CONV3_BIG = 0, TC_CONV3, TC_CONV1, TC_DIRECT, TC_GN, TC_FIR, TC_ATTN, TC_MISC, TC_COUNT };

@@ -17,6 +17,7 @@
 //   cover; same fused producer/epilogue.
 #pragma once
 #include <sgmse_devrt.h>
+#include <type_traits>
 
 namespace sgmse {
 
@@ -38,29 +39,39 @@ struct ConvArgs {
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
-template <int KS, int WC, int FC, int FP>
+template <int KS, int WC, int FC, int FP, int DB = 0>
 struct ConvTile {
   static constexpr int WP = 4 / WC;                 // waves along pixels
   static constexpr int CO_T = WC * FC * 32;         // output channels per workgroup
   static constexpr int ROWS = WP * FP;              // image rows per workgroup (each pixel fragment = 32 px of a row)
-  static constexpr int KC = (KS == 3) ? 8 : 32;     // input channels per LDS stage
+  static constexpr int KC = (KS == 3) ? 8 : 32;     // input-channel granularity of the layer (Cin % KC == 0)
+  static constexpr int NBUF = DB ? 2 : 1;           // LDS stages
+  static constexpr int KCH = KC / NBUF;             // input channels per LDS stage
   static constexpr int HALO = KS / 2;
   static constexpr int RS = 32 + 2 * HALO;          // LDS row stride
   static constexpr int PLANE = (ROWS + 2 * HALO) * RS;
   static constexpr int TAPS = KS * KS;
-  static constexpr int IN_ELEMS = KC * PLANE;
-  static constexpr int W_ELEMS = KC * TAPS * CO_T;
+  static constexpr int IN_ELEMS = KCH * PLANE;
+  static constexpr int W_ELEMS = KCH * TAPS * CO_T;
   static constexpr int NI = (IN_ELEMS + 255) / 256;
   static constexpr int NW4 = (W_ELEMS / 4 + 255) / 256;
 };
 
-template <int KS, int WC, int FC, int FP, int MINW>
+// DB = 0: one LDS stage of KC channels, two barriers per stage, next stage prefetched into registers during the MFMAs.
+// DB = 1: two LDS stages of KC/2 channels (same LDS footprint): the stage after next is fetched into registers and the
+//         next stage written to the idle LDS buffer inside the same basic block as the current stage's MFMAs (one
+//         barrier per stage), so a wave's own staging work sits in the shadow of its own MFMAs.
+// SCHED: 0 compiler default, 1 = __builtin_amdgcn_iglp_opt(0) on the MFMA block, 3 = s_setprio(1) around it.
+template <int KS, int WC, int FC, int FP, int MINW, int DB, int SCHED>
 __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
-  using T = ConvTile<KS, WC, FC, FP>;
-  constexpr int CO_T = T::CO_T, ROWS = T::ROWS, KC = T::KC, HALO = T::HALO, RS = T::RS, PLANE = T::PLANE,
-                TAPS = T::TAPS, NI = T::NI, NW4 = T::NW4;
-  __shared__ float s_in[T::IN_ELEMS];
-  __shared__ float s_w[T::W_ELEMS];
+  using T = ConvTile<KS, WC, FC, FP, DB>;
+  constexpr int CO_T = T::CO_T, ROWS = T::ROWS, KCH = T::KCH, HALO = T::HALO, RS = T::RS, PLANE = T::PLANE,
+                TAPS = T::TAPS, NI = T::NI, NW4 = T::NW4, NBUF = T::NBUF;
+  // the two stages are separate objects so that the compiler knows LDS writes of one never alias reads of the other
+  __shared__ float s_in0[T::IN_ELEMS];
+  __shared__ float s_w0[T::W_ELEMS];
+  __shared__ float s_in1[DB ? T::IN_ELEMS : 4];
+  __shared__ float s_w1[DB ? T::W_ELEMS : 4];
   __shared__ float s_sc[512];
   __shared__ float s_sh[512];
 
@@ -77,12 +88,12 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
   const int H = p.H, W = p.W;
   const bool xform = p.in_scale != nullptr;
 
-  if (xform) {
-    for (int c = tid; c < Cin; c += 256) {
-      s_sc[c] = p.in_scale[b * Cin + c];
-      s_sh[c] = p.in_shift[b * Cin + c];
-    }
+  // fused producer coefficients; identity when there is none, so the staging code below is branch-free
+  for (int c = tid; c < Cin; c += 256) {
+    s_sc[c] = xform ? p.in_scale[b * Cin + c] : 1.f;
+    s_sh[c] = xform ? p.in_shift[b * Cin + c] : 0.f;
   }
+  const bool act = xform && p.in_act;
 
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
   const int wc = wave % WC, wp = wave / WC;
@@ -100,87 +111,84 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
   float rin[NI];
   f32x4 rw[NW4];
   unsigned okmask = 0;
+  int goff[NI];   // offset of the element inside its channel plane (clamped into the image: loads are unconditional)
 
   const float* wbase = p.w + (size_t)co_blk * Cin * TAPS * CO_T;
+  const size_t HW = (size_t)H * W;
 
-  // Per-thread staging coordinates do not depend on the chunk: precompute the validity mask once.
+  // Per-thread staging coordinates do not depend on the chunk.  Threads past the end of the tile re-stage its last
+  // element (same address, same value), which keeps every load and LDS store unconditional.
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int e = tid + 256 * i;
+    int e = tid + 256 * i;
+    e = e < T::IN_ELEMS ? e : T::IN_ELEMS - 1;
     const int c = e / PLANE;
     const int rem = e - c * PLANE;
     const int r = rem / RS;
     const int x = rem - r * RS;
     const int gy = y0 - HALO + r, gx = x0 - HALO + x;
-    const bool ok = (e < T::IN_ELEMS) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
     okmask |= (ok ? 1u : 0u) << i;
+    goff[i] = ok ? gy * W + gx : 0;
   }
 
   auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int e = tid + 256 * i;
-      const int c = e / PLANE;
-      const int rem = e - c * PLANE;
-      const int r = rem / RS;
-      const int x = rem - r * RS;
-      const int gy = y0 - HALO + r, gx = x0 - HALO + x;
-      const int cg = c0 + c;
-      float v = 0.f;
-      if ((okmask >> i) & 1u) {
-        const float* sp = (cg < p.C1) ? p.src1 + ((size_t)(b * p.C1 + cg) * H + gy) * W + gx
-                                      : p.src2 + ((size_t)(b * p.C2 + (cg - p.C1)) * H + gy) * W + gx;
-        v = *sp;
-      }
-      rin[i] = v;
+      int e = tid + 256 * i;
+      e = e < T::IN_ELEMS ? e : T::IN_ELEMS - 1;
+      const int cg = c0 + e / PLANE;
+      const float* plane = (cg < p.C1) ? p.src1 + (size_t)(b * p.C1 + cg) * HW : p.src2 + (size_t)(b * p.C2 + (cg - p.C1)) * HW;
+      rin[i] = plane[goff[i]];
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(wbase + (size_t)c0 * TAPS * CO_T);
 #pragma unroll
     for (int i = 0; i < NW4; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < T::W_ELEMS / 4) rw[i] = wsrc[idx];
+      int idx = tid + 256 * i;
+      idx = idx < T::W_ELEMS / 4 ? idx : T::W_ELEMS / 4 - 1;
+      rw[i] = wsrc[idx];
     }
   };
 
-  auto store_chunk = [&](int c0) {
+  auto store_chunk = [&](int c0, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    float* din = BUF ? s_in1 : s_in0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int e = tid + 256 * i;
-      if (e < T::IN_ELEMS) {
-        float v = rin[i];
-        if (xform && ((okmask >> i) & 1u)) {
-          const int cg = c0 + e / PLANE;
-          v = v * s_sc[cg] + s_sh[cg];
-          if (p.in_act) v = silu_f(v);
-        }
-        s_in[e] = v;
-      }
+      int e = tid + 256 * i;
+      e = e < T::IN_ELEMS ? e : T::IN_ELEMS - 1;
+      const int cg = c0 + e / PLANE;
+      float v = rin[i] * s_sc[cg] + s_sh[cg];
+      const float sv = silu_f(v);
+      v = act ? sv : v;
+      din[e] = ((okmask >> i) & 1u) ? v : 0.f;
     }
-    f32x4* wdst = reinterpret_cast<f32x4*>(s_w);
+    f32x4* wdst = reinterpret_cast<f32x4*>(BUF ? s_w1 : s_w0);
 #pragma unroll
     for (int i = 0; i < NW4; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < T::W_ELEMS / 4) wdst[idx] = rw[i];
+      int idx = tid + 256 * i;
+      idx = idx < T::W_ELEMS / 4 ? idx : T::W_ELEMS / 4 - 1;
+      wdst[idx] = rw[i];
     }
   };
 
-  const int nchunks = Cin / KC;
-  load_chunk(0);
-  __syncthreads();  // s_sc / s_sh visible
-  for (int ci = 0; ci < nchunks; ++ci) {
-    store_chunk(ci * KC);
-    __syncthreads();
-    if (ci + 1 < nchunks) load_chunk((ci + 1) * KC);
-#pragma unroll 1
-    for (int cp = 0; cp < KC / 2; ++cp) {
+  auto compute = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    const float* sw = (BUF ? s_w1 : s_w0) + a_off;
+    const float* si = (BUF ? s_in1 : s_in0) + b_off;
+    if (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
+    if (SCHED == 3) __builtin_amdgcn_s_setprio(1);
+    constexpr int UNR = DB ? KCH / 2 : 1;
+#pragma unroll UNR
+    for (int cp = 0; cp < KCH / 2; ++cp) {
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap) {
         const int dy = tap / KS, dx = tap % KS;
         float a[FC], bb[FP];
 #pragma unroll
-        for (int i = 0; i < FC; ++i) a[i] = s_w[a_off + i * 32 + (cp * 2 * TAPS + tap) * CO_T];
+        for (int i = 0; i < FC; ++i) a[i] = sw[i * 32 + (cp * 2 * TAPS + tap) * CO_T];
 #pragma unroll
-        for (int j = 0; j < FP; ++j) bb[j] = s_in[b_off + j * RS + cp * 2 * PLANE + dy * RS + dx];
+        for (int j = 0; j < FP; ++j) bb[j] = si[j * RS + cp * 2 * PLANE + dy * RS + dx];
 #pragma unroll
         for (int i = 0; i < FC; ++i)
 #pragma unroll
@@ -188,7 +196,63 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
       }
     }
+    if (SCHED == 3) __builtin_amdgcn_s_setprio(0);
+    if (SCHED == 2 && DB) {
+      // Software-pipeline template for the steady-state block (LLVM IGroupLP): the next stage's transform + LDS writes
+      // and the stage-after-next's global loads are spread through the MFMA stream instead of running ahead of it.
+      constexpr int NM = (KCH / 2) * TAPS * FC * FP;
+      __builtin_amdgcn_sched_group_barrier(0x100, FC + FP, 0);   // operands of the first k-step
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // <= 1 LDS read
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                       // <= 4 VALU (transform / address maths)
+        if (i % 6 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // LDS write of the next stage
+        if (i >= NM / 2 && i % 6 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // global load, stage after next
+      }
+    }
+  };
+
+  const int nchunks = Cin / KCH;
+  load_chunk(0);
+  __syncthreads();  // s_sc / s_sh visible
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  if (DB) {
+    store_chunk(0, B0{});
+    if (nchunks > 1) load_chunk(KCH);
     __syncthreads();
+    int ci = 0;
+    for (; ci + 3 < nchunks; ci += 2) {   // steady state, ci even: stage ci+1 -> LDS, fetch ci+2, MFMAs of ci; then the mirror
+      store_chunk((ci + 1) * KCH, B1{});
+      load_chunk((ci + 2) * KCH);
+      compute(B0{});
+      __syncthreads();
+      store_chunk((ci + 2) * KCH, B0{});
+      load_chunk((ci + 3) * KCH);
+      compute(B1{});
+      __syncthreads();
+    }
+    for (; ci < nchunks; ++ci) {          // drain (at most 3 stages)
+      if ((ci & 1) == 0) {
+        if (ci + 1 < nchunks) store_chunk((ci + 1) * KCH, B1{});
+        if (ci + 2 < nchunks) load_chunk((ci + 2) * KCH);
+        compute(B0{});
+      } else {
+        if (ci + 1 < nchunks) store_chunk((ci + 1) * KCH, B0{});
+        if (ci + 2 < nchunks) load_chunk((ci + 2) * KCH);
+        compute(B1{});
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int ci = 0; ci < nchunks; ++ci) {
+      store_chunk(ci * KCH, B0{});
+      __syncthreads();
+      if (ci + 1 < nchunks) load_chunk((ci + 1) * KCH);
+      compute(B0{});
+      __syncthreads();
+    }
   }
 
   // epilogue
@@ -327,25 +391,41 @@ inline void pack_conv_weights(const float* src, float* dst, int ks, int cin, int
         }
 }
 
-// Register-allocation target of the 128x256 tile: 2 = two workgroups per CU (256 VGPRs), 1 = one (512 VGPRs).
-// Chosen once per process from SGMSE_CONV_MINW (measurement knob; default 2).
-inline int conv_minw() {
-  static int v = [] { const char* e = getenv("SGMSE_CONV_MINW"); return (e && e[0] == '1') ? 1 : 2; }();
+// Kernel variant of the MFMA convolution, chosen once per process from SGMSE_CONV_VARIANT (measurement knob):
+//   bit 0      : DB (two LDS stages of KC/2 channels, one barrier per stage)
+//   bits 1..2  : SCHED (0 default, 1 iglp_opt(0), 3 s_setprio around the MFMA block; iglp_opt(1) crashes hipcc 7.2)
+//   bit 3      : register target of one workgroup per CU (512 VGPRs) instead of two
+// Variants other than the default are compiled for the 128x256 tiles only.
+#ifndef SGMSE_CONV_DEFAULT_VARIANT
+#define SGMSE_CONV_DEFAULT_VARIANT 0
+#endif
+inline int conv_variant() {
+  static int v = [] { const char* e = getenv("SGMSE_CONV_VARIANT"); return e ? atoi(e) : SGMSE_CONV_DEFAULT_VARIANT; }();
   return v;
 }
 
 template <int KS, int WC, int FC, int FP>
-inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st) {
+inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant = -1) {
   using T = ConvTile<KS, WC, FC, FP>;
   const int tiles = a.B * ((a.H + T::ROWS - 1) / T::ROWS) * ((a.W + 31) / 32);
   dim3 grid(tiles, (a.Cout + T::CO_T - 1) / T::CO_T, 1);
-  if (FC * FP == 8 && conv_minw() == 1) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1>), grid, dim3(256), st, a);
-  else DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2>), grid, dim3(256), st, a);
+  if (variant < 0) variant = conv_variant();
+  if constexpr (FC * FP == 8) {
+    switch (variant) {
+#define SGMSE_V(ID, MINW_, DB_, SCHED_) \
+      case ID: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, MINW_, DB_, SCHED_>), grid, dim3(256), st, a); return;
+      SGMSE_V(1, 2, 1, 0) SGMSE_V(2, 2, 0, 1) SGMSE_V(3, 2, 1, 1) SGMSE_V(5, 2, 1, 2)
+      SGMSE_V(6, 2, 0, 3) SGMSE_V(7, 2, 1, 3) SGMSE_V(8, 1, 0, 0) SGMSE_V(9, 1, 1, 0)
+#undef SGMSE_V
+      default: break;
+    }
+  }
+  DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 0, 0>), grid, dim3(256), st, a);
 }
 
-inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st) {
+inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1) {
 #define SGMSE_CONV_CASE(KS_, CO_, ROWS_, WC_, FC_, FP_) \
-  if (ks == KS_ && pl.co_t == CO_ && pl.rows == ROWS_) { launch_conv_mfma_t<KS_, WC_, FC_, FP_>(a, st); return; }
+  if (ks == KS_ && pl.co_t == CO_ && pl.rows == ROWS_) { launch_conv_mfma_t<KS_, WC_, FC_, FP_>(a, st, variant); return; }
   SGMSE_CONV_CASE(3, 128, 8, 2, 2, 4)
   SGMSE_CONV_CASE(3, 64, 8, 2, 1, 4)
   SGMSE_CONV_CASE(3, 32, 8, 1, 1, 2)

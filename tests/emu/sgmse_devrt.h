@@ -54,6 +54,10 @@ static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width;
 static inline float __shfl(float v, int lane, int width = 64) { (void)width; return emu::shfl_idx(v, lane); }
 static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) { return emu::mfma_32x32x2(a, b, c); }
 static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) { return emu::mfma_16x16x4(a, b, c); }
+#define __builtin_amdgcn_iglp_opt(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float atomicAdd(float* p, float v) {
   uint32_t* ip = reinterpret_cast<uint32_t*>(p);

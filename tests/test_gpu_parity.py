@@ -151,7 +151,7 @@ def test_error_behaviour(hip):
     from sgmse_amd import ops
     with pytest.raises(ValueError):
         ops.conv2d(torch.zeros(1, 8, 4, 4, device=hip), torch.zeros(8, 8, 5, 5, device=hip))
-    with pytest.raises(ValueError):
+    with pytest.raises(RuntimeError, match="no CPU path"):
         ops.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 3, 3, device=hip))       # CPU tensor: no CPU path
     cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
     net, _ = P.make_backbone(cfg, hip)

@@ -1,22 +1,28 @@
 #!/bin/bash
-# One GPU-box visit: smoke, GPU parity tests, bench (+ A/B of the conv register target), rocprofv3 kernel trace.
-# Everything is logged under gpurun_out/ (merged back by gpurun).
+# One GPU-box visit: smoke, GPU parity tests, conv micro-benchmark (+PMC), bench, rocprofv3 kernel trace.
+# Everything is logged under gpurun_out/ (merged back by gpurun).  Steps are selected by STEPS (default: all).
 set +e
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt
-nproc >> gpurun_out/gpu.txt
-echo "== smoke" ; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/smoke.log
-echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -q --maxfail=12 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_gpu.log
-echo "== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 > gpurun_out/bench.log 2>gpurun_out/bench.err; echo "bench rc=$?"; cat gpurun_out/bench.log; tail -5 gpurun_out/bench.err
-if [ -n "$AB_MINW" ]; then
-  echo "== bench MINW=1"; SGMSE_CONV_MINW=1 timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_minw1.log 2>gpurun_out/bench_minw1.err; cat gpurun_out/bench_minw1.log
+STEPS=${STEPS:-smoke,pytest,micro,pmc,bench,rocprof}
+has() { [[ ",$STEPS," == *",$1,"* ]]; }
+rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
+if has smoke; then echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log; fi
+if has pytest; then echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -q --maxfail=12 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -12 gpurun_out/pytest_gpu.log; fi
+if has micro; then echo "== conv microbench"; timeout 900 python tools/conv_microbench.py > gpurun_out/conv_microbench.log 2>&1; echo "micro rc=$?"; cat gpurun_out/conv_microbench.log | tail -80; fi
+if has pmc; then
+  echo "== PMC (conv microbench, separate counter passes)"
+  rm -rf gpurun_out/pmc
+  VARIANTS=${PMC_VARIANTS:-0,1} ROUNDS=1 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc/p1 -o p -- python tools/conv_microbench.py > gpurun_out/pmc1.log 2>&1; echo "pmc1 rc=$?"
+  VARIANTS=${PMC_VARIANTS:-0,1} ROUNDS=1 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --output-format csv -d gpurun_out/pmc/p2 -o p -- python tools/conv_microbench.py > gpurun_out/pmc2.log 2>&1; echo "pmc2 rc=$?"
+  tail -3 gpurun_out/pmc1.log; ls -la gpurun_out/pmc/p1 gpurun_out/pmc/p2 2>/dev/null | head
 fi
-echo "== rocprofv3"
-rm -rf gpurun_out/prof
-timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o trace -- python bench.py --steps 1 --warmup 0 --batch ${PROF_BATCH:-8} --no-cpu-baseline > gpurun_out/prof_bench.log 2>gpurun_out/prof.err; echo "rocprof rc=$?"
-find gpurun_out/prof -name "*stats*" | head; 
-f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
-# keep the merged-back payload small: drop the raw per-dispatch trace, keep the stats
-find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
+if has bench; then echo "== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 > gpurun_out/bench.log 2>gpurun_out/bench.err; echo "bench rc=$?"; cat gpurun_out/bench.log; tail -3 gpurun_out/bench.err; fi
+if has rocprof; then
+  echo "== rocprofv3 kernel trace of the bench command"
+  rm -rf gpurun_out/prof
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o trace -- python bench.py --steps 1 --warmup 0 --batch ${PROF_BATCH:-32} --no-cpu-baseline > gpurun_out/prof_bench.log 2>gpurun_out/prof.err; echo "rocprof rc=$?"
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 "$f" | cut -c1-200
+  find gpurun_out/prof -name "*kernel_trace.csv" -size +30M -delete
+fi
