@@ -487,6 +487,7 @@ class Engine {
   float bench_conv(int ks, int B, int Cin, int Cout, int H, int W, int variant, int iters, int fused) {
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
     SG_REQUIRE(pl.mfma, "bench_conv: shape is not MFMA-eligible");
+    if (variant >= 0 && (variant & 512)) { pl.rows = 4; variant &= ~512; }   // measurement knob: 128 co x 128 px tile
     const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * Cout * H * W, nw = (size_t)Cout * Cin * ks * ks;
     const size_t ne = packed_weight_elems(ks, Cin, Cout, pl.co_t);
     float* x = static_cast<float*>(dev_alloc_tmp(nx * 4));

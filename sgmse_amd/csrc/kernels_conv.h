@@ -39,7 +39,7 @@ struct ConvArgs {
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
-template <int KS, int WC, int FC, int FP, int DB = 0>
+template <int KS, int WC, int FC, int FP, int DB = 0, int VEC = 0>
 struct ConvTile {
   static constexpr int WP = 4 / WC;                 // waves along pixels
   static constexpr int CO_T = WC * FC * 32;         // output channels per workgroup
@@ -48,8 +48,15 @@ struct ConvTile {
   static constexpr int NBUF = DB ? 2 : 1;           // LDS stages
   static constexpr int KCH = KC / NBUF;             // input channels per LDS stage
   static constexpr int HALO = KS / 2;
-  static constexpr int RS = 32 + 2 * HALO;          // LDS row stride
-  static constexpr int PLANE = (ROWS + 2 * HALO) * RS;
+  // LDS row: scalar staging packs [halo | 32 px | halo] (stride 34 / 32); vector staging keeps the 32 interior pixels
+  // 16-byte aligned at column 4 with the halo columns at 3 and 36 (stride 40) so they can be written as b128
+  static constexpr int RS = (VEC && HALO) ? 40 : 32 + 2 * HALO;
+  static constexpr int XOFF = (VEC && HALO) ? 3 : 0;   // column of the left-most tap of pixel 0
+  static constexpr int TROWS = ROWS + 2 * HALO;
+  static constexpr int PLANE = TROWS * RS;
+  static constexpr int NVI = KCH * TROWS * 8;          // float4 items per stage (vector staging)
+  static constexpr int NV = (NVI + 255) / 256;
+  static constexpr int NHI = KCH * TROWS * 2 * HALO;   // halo scalars per stage (vector staging)
   static constexpr int TAPS = KS * KS;
   static constexpr int IN_ELEMS = KCH * PLANE;
   static constexpr int W_ELEMS = KCH * TAPS * CO_T;
@@ -61,12 +68,14 @@ struct ConvTile {
 // DB = 1: two LDS stages of KC/2 channels (same LDS footprint): the stage after next is fetched into registers and the
 //         next stage written to the idle LDS buffer inside the same basic block as the current stage's MFMAs (one
 //         barrier per stage), so a wave's own staging work sits in the shadow of its own MFMAs.
-// SCHED: 0 compiler default, 1 = __builtin_amdgcn_iglp_opt(0) on the MFMA block, 3 = s_setprio(1) around it.
-template <int KS, int WC, int FC, int FP, int MINW, int DB, int SCHED>
+// SCHED: 0 compiler default, 1 = __builtin_amdgcn_iglp_opt(0) on the MFMA block, 3 = s_setprio(1) around it,
+//        4 = explicit operand prefetch one k-step ahead, order pinned with sched_group_barrier.
+template <int KS, int WC, int FC, int FP, int MINW, int DB, int SCHED, int VEC>
 __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
-  using T = ConvTile<KS, WC, FC, FP, DB>;
+  using T = ConvTile<KS, WC, FC, FP, DB, VEC>;
   constexpr int CO_T = T::CO_T, ROWS = T::ROWS, KCH = T::KCH, HALO = T::HALO, RS = T::RS, PLANE = T::PLANE,
-                TAPS = T::TAPS, NI = T::NI, NW4 = T::NW4, NBUF = T::NBUF;
+                TAPS = T::TAPS, NI = VEC ? 1 : T::NI, NW4 = T::NW4, NBUF = T::NBUF, NV = VEC ? T::NV : 1,
+                TROWS = T::TROWS;
   // the two stages are separate objects so that the compiler knows LDS writes of one never alias reads of the other
   __shared__ float s_in0[T::IN_ELEMS];
   __shared__ float s_w0[T::W_ELEMS];
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
   const int wc = wave % WC, wp = wave / WC;
   const int a_off = kh * TAPS * CO_T + wc * FC * 32 + l31;
-  const int b_off = kh * PLANE + (wp * FP) * RS + l31;
+  const int b_off = kh * PLANE + (wp * FP) * RS + l31 + T::XOFF;
 
   f32x16 acc[FC][FP];
 #pragma unroll
@@ -109,37 +118,84 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float rin[NI];
+  f32x4 rv[NV];
   f32x4 rw[NW4];
   unsigned okmask = 0;
-  int goff[NI];   // offset of the element inside its channel plane (clamped into the image: loads are unconditional)
+  int goff[NI];    // scalar items: offset inside the channel plane (clamped into the image: loads are unconditional)
+  int goff_v[NV];  // vector items: same, for the 16-byte aligned float4 of 4 consecutive pixels
+  int loff_v[NV];  // vector items: LDS offset inside the stage
+  int loff_h = 0;  // halo item: LDS offset inside the stage
 
   const float* wbase = p.w + (size_t)co_blk * Cin * TAPS * CO_T;
   const size_t HW = (size_t)H * W;
 
-  // Per-thread staging coordinates do not depend on the chunk.  Threads past the end of the tile re-stage its last
-  // element (same address, same value), which keeps every load and LDS store unconditional.
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    int e = tid + 256 * i;
-    e = e < T::IN_ELEMS ? e : T::IN_ELEMS - 1;
-    const int c = e / PLANE;
-    const int rem = e - c * PLANE;
-    const int r = rem / RS;
-    const int x = rem - r * RS;
-    const int gy = y0 - HALO + r, gx = x0 - HALO + x;
-    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    okmask |= (ok ? 1u : 0u) << i;
-    goff[i] = ok ? gy * W + gx : 0;
-  }
-
-  auto load_chunk = [&](int c0) {
+  // Per-thread staging coordinates do not depend on the chunk.  Threads past the end of the item list re-stage the last
+  // item (same address, same value), which keeps every load and LDS store unconditional (no divergent branches).
+  if constexpr (!VEC) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       int e = tid + 256 * i;
       e = e < T::IN_ELEMS ? e : T::IN_ELEMS - 1;
-      const int cg = c0 + e / PLANE;
-      const float* plane = (cg < p.C1) ? p.src1 + (size_t)(b * p.C1 + cg) * HW : p.src2 + (size_t)(b * p.C2 + (cg - p.C1)) * HW;
-      rin[i] = plane[goff[i]];
+      const int c = e / PLANE;
+      const int rem = e - c * PLANE;
+      const int r = rem / RS;
+      const int x = rem - r * RS;
+      const int gy = y0 - HALO + r, gx = x0 - HALO + x;
+      const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      okmask |= (ok ? 1u : 0u) << i;
+      goff[i] = ok ? gy * W + gx : 0;
+    }
+  } else {
+    // vector staging (W % 4 == 0): the 32 interior pixels of a tile row are 8 aligned float4; halo columns are scalars
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int it = tid + 256 * i;
+      it = it < T::NVI ? it : T::NVI - 1;
+      const int c = it / (TROWS * 8);
+      const int rem = it - c * (TROWS * 8);
+      const int r = rem >> 3, q = rem & 7;
+      const int gy = y0 - HALO + r, gx = x0 + 4 * q;
+      const bool ok = gy >= 0 && gy < H && gx < W;
+      okmask |= (ok ? 1u : 0u) << i;
+      goff_v[i] = ok ? gy * W + gx : 0;
+      loff_v[i] = c * PLANE + r * RS + (HALO ? 4 : 0) + 4 * q;
+    }
+    if (HALO) {
+      int it = tid < T::NHI ? tid : T::NHI - 1;
+      const int c = it / (TROWS * 2);
+      const int rem = it - c * (TROWS * 2);
+      const int r = rem >> 1, side = rem & 1;
+      const int gy = y0 - HALO + r, gx = side ? x0 + 32 : x0 - 1;
+      const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      okmask |= (ok ? 1u : 0u) << 31;
+      goff[0] = ok ? gy * W + gx : 0;
+      loff_h = c * PLANE + r * RS + (side ? 36 : 3);
+    }
+  }
+
+  auto plane_of = [&](int cg) -> const float* {
+    return (cg < p.C1) ? p.src1 + (size_t)(b * p.C1 + cg) * HW : p.src2 + (size_t)(b * p.C2 + (cg - p.C1)) * HW;
+  };
+
+  auto load_chunk = [&](int c0) {
+    if constexpr (!VEC) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        int e = tid + 256 * i;
+        e = e < T::IN_ELEMS ? e : T::IN_ELEMS - 1;
+        rin[i] = plane_of(c0 + e / PLANE)[goff[i]];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        int it = tid + 256 * i;
+        it = it < T::NVI ? it : T::NVI - 1;
+        rv[i] = *reinterpret_cast<const f32x4*>(plane_of(c0 + it / (TROWS * 8)) + goff_v[i]);
+      }
+      if (HALO) {
+        const int it = tid < T::NHI ? tid : T::NHI - 1;
+        rin[0] = plane_of(c0 + it / (TROWS * 2))[goff[0]];
+      }
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(wbase + (size_t)c0 * TAPS * CO_T);
 #pragma unroll
@@ -150,18 +206,42 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
     }
   };
 
+  auto xf1 = [&](float v, float sc, float sh, bool ok) -> float {
+    v = v * sc + sh;
+    const float sv = silu_f(v);
+    v = act ? sv : v;
+    return ok ? v : 0.f;
+  };
+
   auto store_chunk = [&](int c0, auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
     float* din = BUF ? s_in1 : s_in0;
+    if constexpr (!VEC) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      int e = tid + 256 * i;
-      e = e < T::IN_ELEMS ? e : T::IN_ELEMS - 1;
-      const int cg = c0 + e / PLANE;
-      float v = rin[i] * s_sc[cg] + s_sh[cg];
-      const float sv = silu_f(v);
-      v = act ? sv : v;
-      din[e] = ((okmask >> i) & 1u) ? v : 0.f;
+      for (int i = 0; i < NI; ++i) {
+        int e = tid + 256 * i;
+        e = e < T::IN_ELEMS ? e : T::IN_ELEMS - 1;
+        const int cg = c0 + e / PLANE;
+        din[e] = xf1(rin[i], s_sc[cg], s_sh[cg], (okmask >> i) & 1u);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        int it = tid + 256 * i;
+        it = it < T::NVI ? it : T::NVI - 1;
+        const int cg = c0 + it / (TROWS * 8);
+        const float sc = s_sc[cg], sh = s_sh[cg];
+        const bool ok = (okmask >> i) & 1u;
+        f32x4 o;
+        o[0] = xf1(rv[i][0], sc, sh, ok); o[1] = xf1(rv[i][1], sc, sh, ok);
+        o[2] = xf1(rv[i][2], sc, sh, ok); o[3] = xf1(rv[i][3], sc, sh, ok);
+        *reinterpret_cast<f32x4*>(din + loff_v[i]) = o;
+      }
+      if (HALO) {
+        const int it = tid < T::NHI ? tid : T::NHI - 1;
+        const int cg = c0 + it / (TROWS * 2);
+        din[loff_h] = xf1(rin[0], s_sc[cg], s_sh[cg], (okmask >> 31) & 1u);
+      }
     }
     f32x4* wdst = reinterpret_cast<f32x4*>(BUF ? s_w1 : s_w0);
 #pragma unroll
@@ -178,6 +258,37 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
     const float* si = (BUF ? s_in1 : s_in0) + b_off;
     if (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
     if (SCHED == 3) __builtin_amdgcn_s_setprio(1);
+    if (SCHED == 4) {
+      // Explicit operand pipeline: the LDS reads of k-step s+1 are issued before the MFMAs of k-step s, so a wave
+      // never parks on lgkmcnt between MFMA groups (two co-resident waves otherwise reach their LDS waits in
+      // lock-step and leave the matrix pipe idle).  The sched_group_barrier template pins that order.
+      constexpr int NS = (KCH / 2) * TAPS;
+      float a[2][FC], bb[2][FP];
+      auto ld = [&](int s2, int slot) {
+        const int cp = s2 / TAPS, tap = s2 % TAPS, dy = tap / KS, dx = tap % KS;
+#pragma unroll
+        for (int i = 0; i < FC; ++i) a[slot][i] = sw[i * 32 + (cp * 2 * TAPS + tap) * CO_T];
+#pragma unroll
+        for (int j = 0; j < FP; ++j) bb[slot][j] = si[j * RS + cp * 2 * PLANE + dy * RS + dx];
+      };
+      ld(0, 0);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        if (s2 + 1 < NS) ld(s2 + 1, (s2 + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < FC; ++i)
+#pragma unroll
+          for (int j = 0; j < FP; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2 & 1][i], bb[s2 & 1][j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, FC + FP, 0);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        if (s2 + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, FC + FP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, FC * FP, 0);
+      }
+      return;
+    }
     constexpr int UNR = DB ? KCH / 2 : 1;
 #pragma unroll UNR
     for (int cp = 0; cp < KCH / 2; ++cp) {
@@ -197,20 +308,6 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
       }
     }
     if (SCHED == 3) __builtin_amdgcn_s_setprio(0);
-    if (SCHED == 2 && DB) {
-      // Software-pipeline template for the steady-state block (LLVM IGroupLP): the next stage's transform + LDS writes
-      // and the stage-after-next's global loads are spread through the MFMA stream instead of running ahead of it.
-      constexpr int NM = (KCH / 2) * TAPS * FC * FP;
-      __builtin_amdgcn_sched_group_barrier(0x100, FC + FP, 0);   // operands of the first k-step
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // <= 1 LDS read
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                       // <= 4 VALU (transform / address maths)
-        if (i % 6 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // LDS write of the next stage
-        if (i >= NM / 2 && i % 6 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // global load, stage after next
-      }
-    }
   };
 
   const int nchunks = Cin / KCH;
@@ -365,7 +462,10 @@ struct ConvPlan { int co_t; int rows; bool mfma; };
 inline ConvPlan choose_conv_plan(int ks, int cin, int cout, int H, int W) {
   ConvPlan pl{0, 0, false};
   const int kc = (ks == 3) ? 8 : 32;
-  if ((ks != 1 && ks != 3) || cin % kc != 0 || cin > 512 || cout % 32 != 0) return pl;
+  if ((ks != 1 && ks != 3) || cin % kc != 0 || cin > 512) return pl;
+  // thin outputs (the C->4 pyramid convolutions) run on a zero-padded 32-channel MFMA tile when the reduction is deep
+  // enough to pay for it; thin inputs (4->C) stay on the direct kernel
+  if (cout % 32 != 0 && !(cout < 32 && cin >= 64)) return pl;
   pl.mfma = true;
   pl.co_t = (cout % 128 == 0) ? 128 : (cout % 64 == 0 ? 64 : 32);
   pl.rows = (H >= 8) ? 8 : 4;
@@ -392,9 +492,9 @@ inline void pack_conv_weights(const float* src, float* dst, int ks, int cin, int
 }
 
 // Kernel variant of the MFMA convolution, chosen once per process from SGMSE_CONV_VARIANT (measurement knob):
-//   bit 0      : DB (two LDS stages of KC/2 channels, one barrier per stage)
-//   bits 1..2  : SCHED (0 default, 1 iglp_opt(0), 3 s_setprio around the MFMA block; iglp_opt(1) crashes hipcc 7.2)
-//   bit 3      : register target of one workgroup per CU (512 VGPRs) instead of two
+//   0 default | 1 double-buffered LDS stages | 4 operand prefetch pinned with sched_group_barrier | 5 = 1+4 |
+//   6 s_setprio around the MFMA block | +256 scalar input staging.  (iglp_opt(1) crashes hipcc 7.2; iglp_opt(0) and a
+//   one-workgroup-per-CU register target measured no better, see DESIGN.md.)
 // Variants other than the default are compiled for the 128x256 tiles only.
 #ifndef SGMSE_CONV_DEFAULT_VARIANT
 #define SGMSE_CONV_DEFAULT_VARIANT 0
@@ -404,8 +504,8 @@ inline int conv_variant() {
   return v;
 }
 
-template <int KS, int WC, int FC, int FP>
-inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant = -1) {
+template <int KS, int WC, int FC, int FP, int VEC>
+inline void launch_conv_mfma_v(const ConvArgs& a, drt::stream_t st, int variant) {
   using T = ConvTile<KS, WC, FC, FP>;
   const int tiles = a.B * ((a.H + T::ROWS - 1) / T::ROWS) * ((a.W + 31) / 32);
   dim3 grid(tiles, (a.Cout + T::CO_T - 1) / T::CO_T, 1);
@@ -413,14 +513,23 @@ inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant 
   if constexpr (FC * FP == 8) {
     switch (variant) {
 #define SGMSE_V(ID, MINW_, DB_, SCHED_) \
-      case ID: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, MINW_, DB_, SCHED_>), grid, dim3(256), st, a); return;
-      SGMSE_V(1, 2, 1, 0) SGMSE_V(2, 2, 0, 1) SGMSE_V(3, 2, 1, 1) SGMSE_V(5, 2, 1, 2)
-      SGMSE_V(6, 2, 0, 3) SGMSE_V(7, 2, 1, 3) SGMSE_V(8, 1, 0, 0) SGMSE_V(9, 1, 1, 0)
+      case ID: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, MINW_, DB_, SCHED_, VEC>), grid, dim3(256), st, a); return;
+      SGMSE_V(1, 2, 1, 0) SGMSE_V(4, 2, 0, 4) SGMSE_V(5, 2, 1, 4) SGMSE_V(6, 2, 0, 3)
 #undef SGMSE_V
       default: break;
     }
   }
-  DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 0, 0>), grid, dim3(256), st, a);
+  DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 0, 0, VEC>), grid, dim3(256), st, a);
+}
+
+// variant bit 8 (256): scalar (element-wise) input staging even when the row length allows float4 staging
+template <int KS, int WC, int FC, int FP>
+inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant = -1) {
+  if (variant < 0) variant = conv_variant();
+  const bool vec = (a.W % 4 == 0) && !(variant & 256) && a.src1 != nullptr &&
+                   (reinterpret_cast<uintptr_t>(a.src1) % 16 == 0) && (a.src2 == nullptr || reinterpret_cast<uintptr_t>(a.src2) % 16 == 0);
+  if (vec) launch_conv_mfma_v<KS, WC, FC, FP, 1>(a, st, variant & 255);
+  else launch_conv_mfma_v<KS, WC, FC, FP, 0>(a, st, variant & 255);
 }
 
 inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1) {
