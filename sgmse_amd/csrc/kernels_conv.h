@@ -70,8 +70,14 @@ struct ConvTile {
 //         barrier per stage), so a wave's own staging work sits in the shadow of its own MFMAs.
 // SCHED: 0 compiler default, 1 = __builtin_amdgcn_iglp_opt(0) on the MFMA block, 3 = s_setprio(1) around it,
 //        4 = explicit operand prefetch one k-step ahead, order pinned with sched_group_barrier.
-template <int KS, int WC, int FC, int FP, int MINW, int DB, int SCHED, int VEC>
-__global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
+// WS = 1: wave-specialised workgroup of 512 threads (requires DB): waves 0-3 only read LDS and issue MFMAs, waves 4-7 only
+//         stage (global loads, fused GroupNorm/SiLU, LDS writes) the next K-stage into the idle buffer.  The matrix pipe of
+//         every SIMD is then fed by a wave that never leaves its MFMA stream, while its partner wave on the same SIMD uses the
+//         VALU/LDS/VMEM issue slots in between (the two blocks-per-CU arrangement of WS = 0 runs its staging phases in
+//         lock-step and leaves the pipe ~20 % idle: profiles/r01_pmc_conv_microbench.json).
+template <int KS, int WC, int FC, int FP, int MINW, int DB, int SCHED, int VEC, int WS = 0>
+__global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArgs p) {
+  static_assert(!WS || DB, "wave specialisation needs the two-stage LDS layout");
   using T = ConvTile<KS, WC, FC, FP, DB, VEC>;
   constexpr int CO_T = T::CO_T, ROWS = T::ROWS, KCH = T::KCH, HALO = T::HALO, RS = T::RS, PLANE = T::PLANE,
                 TAPS = T::TAPS, NI = VEC ? 1 : T::NI, NW4 = T::NW4, NBUF = T::NBUF, NV = VEC ? T::NV : 1,
@@ -84,7 +90,9 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
   __shared__ float s_sc[512];
   __shared__ float s_sh[512];
 
-  const int tid = threadIdx.x;
+  constexpr int NT = WS ? 512 : 256;
+  const bool producer = WS && threadIdx.x >= 256;
+  const int tid = threadIdx.x & 255;   // staging index (producers) / MFMA index (consumers)
   const int Cin = p.C1 + p.C2;
   const int tiles_x = (p.W + 31) >> 5;
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
   const bool xform = p.in_scale != nullptr;
 
   // fused producer coefficients; identity when there is none, so the staging code below is branch-free
-  for (int c = tid; c < Cin; c += 256) {
+  for (int c = threadIdx.x; c < Cin; c += NT) {
     s_sc[c] = xform ? p.in_scale[b * Cin + c] : 1.f;
     s_sh[c] = xform ? p.in_shift[b * Cin + c] : 0.f;
   }
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
     const float* sw = (BUF ? s_w1 : s_w0) + a_off;
     const float* si = (BUF ? s_in1 : s_in0) + b_off;
     if (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
-    if (SCHED == 3) __builtin_amdgcn_s_setprio(1);
+    if (SCHED == 3 && !WS) __builtin_amdgcn_s_setprio(1);
     if (SCHED == 4) {
       // Explicit operand pipeline: the LDS reads of k-step s+1 are issued before the MFMAs of k-step s, so a wave
       // never parks on lgkmcnt between MFMA groups (two co-resident waves otherwise reach their LDS waits in
@@ -307,42 +315,31 @@ __global__ __launch_bounds__(256, MINW) void conv_mfma_kernel(ConvArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (SCHED == 3) __builtin_amdgcn_s_setprio(0);
+    if (SCHED == 3 && !WS) __builtin_amdgcn_s_setprio(0);
   };
 
   const int nchunks = Cin / KCH;
-  load_chunk(0);
+  if (!WS || producer) load_chunk(0);
   __syncthreads();  // s_sc / s_sh visible
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  if (DB) {
-    store_chunk(0, B0{});
-    if (nchunks > 1) load_chunk(KCH);
+  if (WS) {
+    if (producer) { store_chunk(0, B0{}); }
     __syncthreads();
-    int ci = 0;
-    for (; ci + 3 < nchunks; ci += 2) {   // steady state, ci even: stage ci+1 -> LDS, fetch ci+2, MFMAs of ci; then the mirror
-      store_chunk((ci + 1) * KCH, B1{});
-      load_chunk((ci + 2) * KCH);
-      compute(B0{});
+    if (SCHED == 3 && !producer) __builtin_amdgcn_s_setprio(1);
+    for (int ci = 0; ci < nchunks; ci += 2) {
+      if (producer) { if (ci + 1 < nchunks) { load_chunk((ci + 1) * KCH); store_chunk((ci + 1) * KCH, B1{}); } }
+      else compute(B0{});
       __syncthreads();
-      store_chunk((ci + 2) * KCH, B0{});
-      load_chunk((ci + 3) * KCH);
-      compute(B1{});
-      __syncthreads();
-    }
-    for (; ci < nchunks; ++ci) {          // drain (at most 3 stages)
-      if ((ci & 1) == 0) {
-        if (ci + 1 < nchunks) store_chunk((ci + 1) * KCH, B1{});
-        if (ci + 2 < nchunks) load_chunk((ci + 2) * KCH);
-        compute(B0{});
-      } else {
-        if (ci + 1 < nchunks) store_chunk((ci + 1) * KCH, B0{});
-        if (ci + 2 < nchunks) load_chunk((ci + 2) * KCH);
-        compute(B1{});
+      if (ci + 1 < nchunks) {
+        if (producer) { if (ci + 2 < nchunks) { load_chunk((ci + 2) * KCH); store_chunk((ci + 2) * KCH, B0{}); } }
+        else compute(B1{});
+        __syncthreads();
       }
-      __syncthreads();
     }
-  } else {
+    if (producer) return;
+  } else if (DB) {
+    store_chunk(0, B0{});  } else {
     for (int ci = 0; ci < nchunks; ++ci) {
       store_chunk(ci * KCH, B0{});
       __syncthreads();
@@ -493,7 +490,8 @@ inline void pack_conv_weights(const float* src, float* dst, int ks, int cin, int
 
 // Kernel variant of the MFMA convolution, chosen once per process from SGMSE_CONV_VARIANT (measurement knob):
 //   0 default | 1 double-buffered LDS stages | 4 operand prefetch pinned with sched_group_barrier | 5 = 1+4 |
-//   6 s_setprio around the MFMA block | +256 scalar input staging.  (iglp_opt(1) crashes hipcc 7.2; iglp_opt(0) and a
+//   6 s_setprio around the MFMA block | 8 wave-specialised (4 MFMA waves + 4 staging waves) | 9 = 8 + s_setprio for the
+//   MFMA waves | 10 = 8 + operand prefetch | +256 scalar input staging.  (iglp_opt(1) crashes hipcc 7.2; iglp_opt(0) and a
 //   one-workgroup-per-CU register target measured no better, see DESIGN.md.)
 // Variants other than the default are compiled for the 128x256 tiles only.
 #ifndef SGMSE_CONV_DEFAULT_VARIANT
@@ -513,13 +511,16 @@ inline void launch_conv_mfma_v(const ConvArgs& a, drt::stream_t st, int variant)
   if constexpr (FC * FP == 8) {
     switch (variant) {
 #define SGMSE_V(ID, MINW_, DB_, SCHED_) \
-      case ID: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, MINW_, DB_, SCHED_, VEC>), grid, dim3(256), st, a); return;
+      case ID: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, MINW_, DB_, SCHED_, VEC, 0>), grid, dim3(256), st, a); return;
       SGMSE_V(1, 2, 1, 0) SGMSE_V(4, 2, 0, 4) SGMSE_V(5, 2, 1, 4) SGMSE_V(6, 2, 0, 3)
 #undef SGMSE_V
+      case 8: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 1, 0, VEC, 1>), grid, dim3(512), st, a); return;
+      case 9: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 1, 3, VEC, 1>), grid, dim3(512), st, a); return;
+      case 10: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 1, 4, VEC, 1>), grid, dim3(512), st, a); return;
       default: break;
     }
   }
-  DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 0, 0, VEC>), grid, dim3(256), st, a);
+  DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 0, 0, VEC, 0>), grid, dim3(256), st, a);
 }
 
 // variant bit 8 (256): scalar (element-wise) input staging even when the row length allows float4 staging

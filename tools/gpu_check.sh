@@ -19,6 +19,17 @@ if has pmc; then
   tail -3 gpurun_out/pmc1.log; ls -la gpurun_out/pmc/p1 gpurun_out/pmc/p2 2>/dev/null | head
 fi
 if has bench; then echo "== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 > gpurun_out/bench.log 2>gpurun_out/bench.err; echo "bench rc=$?"; cat gpurun_out/bench.log; tail -3 gpurun_out/bench.err; fi
+for v in ${BENCH_VARIANTS:-}; do echo "== bench SGMSE_CONV_VARIANT=$v"; SGMSE_CONV_VARIANT=$v timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_v$v.log 2>gpurun_out/bench_v$v.err; cat gpurun_out/bench_v$v.log | cut -c1-200; python -c "
+import json,sys
+d=json.loads(open('gpurun_out/bench_v$v.log').read().strip().splitlines()[-1]); print('variant $v', d['value'], d['roofline']['achieved'], {k:v['ms'] for k,v in d['kernel_classes_one_eval'].items()})"; done
+if has hbm; then
+  echo "== HBM traffic (FETCH_SIZE / WRITE_SIZE passes over the bench command)"
+  rm -rf gpurun_out/hbm
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/hbm/fetch -o p -- python bench.py --steps 1 --warmup 0 --batch ${PROF_BATCH:-32} --no-cpu-baseline --no-profile > gpurun_out/hbm_fetch.log 2>&1; echo "fetch rc=$?"
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/hbm/write -o p -- python bench.py --steps 1 --warmup 0 --batch ${PROF_BATCH:-32} --no-cpu-baseline --no-profile > gpurun_out/hbm_write.log 2>&1; echo "write rc=$?"
+  python tools/summarize_hbm.py gpurun_out/hbm/fetch gpurun_out/hbm/write > gpurun_out/hbm_traffic.json; head -c 1500 gpurun_out/hbm_traffic.json
+  find gpurun_out/hbm -name "*.csv" -size +20M -delete
+fi
 if has rocprof; then
   echo "== rocprofv3 kernel trace of the bench command"
   rm -rf gpurun_out/prof
