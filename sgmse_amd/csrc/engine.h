@@ -224,7 +224,7 @@ class Arena {
   std::map<size_t, size_t> live_;
 };
 
-struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; };
+struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; float* st = nullptr; int nsub = 0; };   // st: [B][C][nsub][2] GroupNorm partial sums
 
 struct ConvW {            // one convolution's parameters on the device
   const float* oihw = nullptr;   // [cout][cin][ks][ks] (for NIN: transposed copy)
@@ -424,9 +424,12 @@ class Engine {
     float* stats = static_cast<float*>(dev_alloc_tmp((size_t)B * C * 2 * 4));
     float* sc = static_cast<float*>(dev_alloc_tmp((size_t)B * C * 4));
     float* sh = static_cast<float*>(dev_alloc_tmp((size_t)B * C * 4));
-    DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C), dim3(256), stream_, x, x2, C1, C2, HW, stats);
+    float* stats2 = stats + (size_t)B * C1 * 2;
+    DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C1), dim3(256), stream_, x, (const float*)nullptr, C1, 0, HW, stats);
+    if (C2) DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C2), dim3(256), stream_, x2, (const float*)nullptr, C2, 0, HW, stats2);
     const int G = std::min(C / 4, 32);
-    DRT_LAUNCH(gn_finalize_kernel, dim3(B), dim3(256), stream_, (const float*)stats, gamma, beta, C, G, HW, 1e-6f, sc, sh);
+    DRT_LAUNCH(gn_finalize_kernel, dim3(B), dim3(256), stream_, (const float*)stats, C1, 1, (const float*)stats2, C2, 1, gamma, beta, G,
+               HW, 1e-6f, sc, sh);
     DRT_LAUNCH(gn_apply_kernel, dim3((HW + 1023) / 1024, B * C), dim3(256), stream_, x, x2, C1, C2, HW, (const float*)sc,
                (const float*)sh, act, out);
     SG_CHECK(drt::stream_sync(stream_));
@@ -719,40 +722,61 @@ class Engine {
   void tock() { if (prof_) { if (!ev_init_) { drt::event_create(&ev_a_); drt::event_create(&ev_b_); ev_init_ = true; } drt::event_record(&ev_a_, stream_); } }
 
   Tensor new_tensor(int C, int H, int W) { Tensor t; t.C = C; t.H = H; t.W = W; t.p = arena_.alloc((size_t)B_ * C * H * W); return t; }
-  void drop(Tensor& t) { arena_.release(t.p); t.p = nullptr; }
+  void drop(Tensor& t) { arena_.release(t.p); t.p = nullptr; if (t.st) { arena_.release(t.st); t.st = nullptr; } }
 
+  // GroupNorm coefficients of the virtual concat [a | b].  Per-channel partial sums come from the producing convolution's
+  // epilogue when it emitted them (Tensor::st), otherwise from one streaming pass over the tensor.
   void gn_coeffs(const Tensor& a, const Tensor* b, const float* gamma, const float* beta, float** sc, float** sh) {
     const int C = a.C + (b ? b->C : 0), HW = a.H * a.W;
-    float* stats = arena_.alloc((size_t)B_ * C * 2);
+    const float* st[2] = {a.st, b ? b->st : nullptr};
+    int nsub[2] = {a.nsub, b ? b->nsub : 0};
+    float* tmp[2] = {nullptr, nullptr};
+    const Tensor* src[2] = {&a, b};
+    for (int k = 0; k < 2; ++k) {
+      if (!src[k] || st[k]) continue;
+      tmp[k] = arena_.alloc((size_t)B_ * src[k]->C * 2);
+      st[k] = tmp[k]; nsub[k] = 1;
+      if (!dry_) {
+        tock();
+        DRT_LAUNCH(gn_chan_stats_kernel, dim3(B_ * src[k]->C), dim3(256), stream_, (const float*)src[k]->p, (const float*)nullptr,
+                   src[k]->C, 0, HW, tmp[k]);
+        tick(TC_GN, 4.0 * B_ * (double)src[k]->C * HW, 1);
+      }
+    }
     *sc = arena_.alloc((size_t)B_ * C);
     *sh = arena_.alloc((size_t)B_ * C);
     if (!dry_) {
       tock();
-      DRT_LAUNCH(gn_chan_stats_kernel, dim3(B_ * C), dim3(256), stream_, (const float*)a.p, (const float*)(b ? b->p : nullptr), a.C,
-                 b ? b->C : 0, HW, stats);
       const int G = std::min(C / 4, 32);
-      DRT_LAUNCH(gn_finalize_kernel, dim3(B_), dim3(256), stream_, (const float*)stats, gamma, beta, C, G, HW, 1e-6f, *sc, *sh);
-      tick(TC_GN, 4.0 * B_ * (double)C * HW, 2);
+      DRT_LAUNCH(gn_finalize_kernel, dim3(B_), dim3(256), stream_, st[0], a.C, nsub[0], st[1], b ? b->C : 0, nsub[1], gamma, beta, G,
+                 HW, 1e-6f, *sc, *sh);
+      tick(TC_GN, 8.0 * B_ * ((double)a.C * nsub[0] + (b ? (double)b->C * nsub[1] : 0.0)), 1);
     }
-    arena_.release(stats);
+    for (int k = 0; k < 2; ++k) if (tmp[k]) arena_.release(tmp[k]);
   }
 
   Tensor conv(const ConvW& w, const Tensor& a, const Tensor* b, const Xform& xf, const float* bias, const float* bias2,
-              const float* res, float out_scale, const FwdCtl& ctl) {
+              const float* res, float out_scale, const FwdCtl& ctl, bool emit_stats = false) {
     const int Cin = a.C + (b ? b->C : 0);
     SG_REQUIRE(Cin == w.cin, "conv: channel mismatch");
     Tensor o = new_tensor(w.cout, a.H, a.W);
+    const int kc_ = (w.ks == 3) ? 8 : 32;
+    const bool use_mfma = w.packed && (b == nullptr || a.C % kc_ == 0);
+    if (emit_stats && use_mfma && fuse_gn_stats_) {
+      o.nsub = conv_plan_nsub(w.co_t, a.H >= 8 ? 8 : 4, a.H, a.W);
+      o.st = arena_.alloc((size_t)B_ * w.cout * o.nsub * 2);
+    }
     if (dry_) return o;
     ConvArgs ca{};
+    ca.stats_out = o.st; ca.stats_nsub = o.nsub;
     ca.src1 = a.p; ca.src2 = b ? b->p : nullptr; ca.C1 = a.C; ca.C2 = b ? b->C : 0;
     ca.bias = bias; ca.bias2 = bias2; ca.bias2_bstride = ctl.bias_bstride; ca.bias2_sstride = ctl.bias_sstride;
     ca.step_ptr = bias2 ? ctl.step_ptr : nullptr;
     ca.in_scale = xf.scale; ca.in_shift = xf.shift; ca.in_act = xf.act;
     ca.res = res; ca.out_scale = out_scale; ca.out = o.p; ca.Cout = w.cout; ca.B = B_; ca.H = a.H; ca.W = a.W;
-    const int kc = (w.ks == 3) ? 8 : 32;
     tock();
     const double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
-    if (w.packed && (ca.C2 == 0 || ca.C1 % kc == 0)) {
+    if (use_mfma) {
       ConvPlan pl{w.co_t, a.H >= 8 ? 8 : 4, true};
       ca.w = w.packed;
       launch_conv_mfma(ca, w.ks, pl, stream_);
@@ -790,10 +814,10 @@ class Engine {
       Tensor hr = fir(a, m.up, x0);
       xs = fir(a, m.up, Xform{});
       have_xs = true;
-      h = conv(r.c0, hr, nullptr, Xform{}, nullptr, temb, nullptr, 1.f, ctl);
+      h = conv(r.c0, hr, nullptr, Xform{}, nullptr, temb, nullptr, 1.f, ctl, true);
       drop(hr);
     } else {
-      h = conv(r.c0, a, b, x0, nullptr, temb, nullptr, 1.f, ctl);
+      h = conv(r.c0, a, b, x0, nullptr, temb, nullptr, 1.f, ctl, true);
     }
     arena_.release(sc0); arena_.release(sh0);
     gn_coeffs(h, nullptr, r.g1w, r.g1b, &sc1, &sh1);
@@ -803,11 +827,11 @@ class Engine {
     if (r.has_c2) {
       Tensor sh_t = have_xs ? conv(r.c2, xs, nullptr, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl)
                             : conv(r.c2, a, b, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl);
-      out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, sh_t.p, inv_sqrt2, ctl);
+      out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, sh_t.p, inv_sqrt2, ctl, true);
       drop(sh_t);
     } else {
       SG_REQUIRE(b == nullptr, "identity shortcut with concat input");
-      out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, a.p, inv_sqrt2, ctl);
+      out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, a.p, inv_sqrt2, ctl, true);
     }
     if (have_xs) drop(xs);
     drop(h);
@@ -830,7 +854,7 @@ class Engine {
       tick(TC_ATTN, 4.0 * B_ * (double)x.C * (x.H * x.W) * (double)(x.H * x.W));
     }
     drop(qkv);
-    Tensor out = conv(w.proj, o, nullptr, Xform{}, w.proj.bias, nullptr, x.p, 0.70710678118654752440f, ctl);
+    Tensor out = conv(w.proj, o, nullptr, Xform{}, w.proj.bias, nullptr, x.p, 0.70710678118654752440f, ctl, true);
     drop(o);
     return out;
   }
@@ -973,6 +997,7 @@ class Engine {
 
   Arena arena_; char* arena_base_ = nullptr; size_t arena_cap_ = 0;
   bool dry_ = false;
+  bool fuse_gn_stats_ = [] { const char* e = getenv("SGMSE_FUSE_GN_STATS"); return !(e && e[0] == '0'); }();   // measurement knob
   int B_ = 0, shape_B_ = 0, shape_F_ = 0, shape_T_ = 0;
   float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr, *sy_ = nullptr; size_t samp_n_ = 0;
   int* step_ctr_ = nullptr;

@@ -163,14 +163,14 @@ __global__ __launch_bounds__(256) void temb_mlp_kernel(TembArgs p) {
     float acc = 0.f;
     const float* wr = p.w1 + (size_t)o * ne;
     for (int i = 0; i < ne; ++i) acc = fmaf(wr[i], s_emb[i], acc);
-    s_h[o] = silu_f(acc + p.b1[o]);
+    s_h[o] = silu_precise_f(acc + p.b1[o]);
   }
   __syncthreads();
   for (int o = threadIdx.x; o < nh; o += 256) {
     float acc = 0.f;
     const float* wr = p.w2 + (size_t)o * nh;
     for (int i = 0; i < nh; ++i) acc = fmaf(wr[i], s_h[i], acc);
-    p.act_out[(size_t)row * nh + o] = silu_f(acc + p.b2[o]);
+    p.act_out[(size_t)row * nh + o] = silu_precise_f(acc + p.b2[o]);
   }
 }
 

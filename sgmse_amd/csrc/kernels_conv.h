@@ -35,9 +35,17 @@ struct ConvArgs {
   float out_scale;         // out = (acc + bias + bias2 + res) * out_scale
   float* out;
   int Cout, B, H, W;
+  // optional GroupNorm statistics of the stored output, fused into the epilogue: per (b, co, sub-tile) partial
+  // {sum, sum of squares}; sub-tile = (tile index in the image) * WP + (pixel-wave index).  Deterministic (no atomics).
+  float* stats_out;
+  int stats_nsub;
 };
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+// SiLU x*sigmoid(x) (nn.SiLU, reference layers.py:38-39) on the hardware exp2/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each,
+// relative error of the result < 4e-7, far inside the 1e-5 per-op parity gate) -- the fused producers evaluate it for every
+// staged element, so a libm-accurate expf + IEEE divide (~25 VALU instructions) would dominate the staging phase.
+__device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_precise_f(float v) { return v / (1.0f + expf(-v)); }   // time-embedding MLP (tiny)
 
 template <int KS, int WC, int FC, int FP, int DB = 0, int VEC = 0>
 struct ConvTile {
@@ -370,6 +378,9 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
       }
       bv[r] = t;
     }
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
 #pragma unroll
     for (int j = 0; j < FP; ++j) {
       const int y = y0 + wp * FP + j;
@@ -381,8 +392,25 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
             const size_t o = ((size_t)(b * p.Cout + co) * H + y) * W + x;
             float v = acc[i][j][r] + bv[r];
             if (p.res) v += p.res[o];
-            p.out[o] = v * p.out_scale;
+            v *= p.out_scale;
+            p.out[o] = v;
+            ssum[r] += v;
+            ssq[r] += v * v;
           }
+        }
+      }
+    }
+    if (p.stats_out) {   // wave-uniform
+      const int sub = (ty * tiles_x + tx) * T::WP + wp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float a1 = ssum[r], a2 = ssq[r];
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) { a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
+        const int co = co_base + (r & 3) + 8 * (r >> 2);
+        if (l31 == 0 && co < p.Cout) {
+          float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + sub) * 2;
+          so[0] = a1; so[1] = a2;
         }
       }
     }
@@ -455,6 +483,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs p) {
 
 // Which MFMA tile a layer uses.  co_t in {32,64,128}; rows in {8,4}.
 struct ConvPlan { int co_t; int rows; bool mfma; };
+inline int conv_plan_wp(int co_t) { return co_t == 32 ? 4 : 2; }            // pixel-waves per workgroup (ConvTile::WP)
+inline int conv_plan_nsub(int co_t, int rows, int H, int W) {                 // statistics sub-tiles per image
+  return ((H + rows - 1) / rows) * ((W + 31) / 32) * conv_plan_wp(co_t);
+}
 
 inline ConvPlan choose_conv_plan(int ks, int cin, int cout, int H, int W) {
   ConvPlan pl{0, 0, false};
@@ -495,7 +527,7 @@ inline void pack_conv_weights(const float* src, float* dst, int ks, int cin, int
 //   one-workgroup-per-CU register target measured no better, see DESIGN.md.)
 // Variants other than the default are compiled for the 128x256 tiles only.
 #ifndef SGMSE_CONV_DEFAULT_VARIANT
-#define SGMSE_CONV_DEFAULT_VARIANT 0
+#define SGMSE_CONV_DEFAULT_VARIANT 4
 #endif
 inline int conv_variant() {
   static int v = [] { const char* e = getenv("SGMSE_CONV_VARIANT"); return e ? atoi(e) : SGMSE_CONV_DEFAULT_VARIANT; }();

@@ -50,18 +50,28 @@ __global__ __launch_bounds__(256) void gn_chan_stats_kernel(const float* src1, c
   }
 }
 
-// grid = B blocks of 256 threads
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* stats, const float* gamma, const float* beta, int C,
-                                                          int G, int HW, float eps, float* scale, float* shift) {
-  const int b = blockIdx.x;
+// Per-(b,c) totals come as `nsub` partial {sum, sumsq} pairs per channel (nsub = 1 from gn_chan_stats_kernel, the number
+// of statistics sub-tiles when a convolution epilogue produced them); the two sources of a virtual concat may differ.
+// grid = B blocks of 256 threads.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* st1, int C1, int nsub1, const float* st2, int C2, int nsub2,
+                                                          const float* gamma, const float* beta, int G, int HW, float eps,
+                                                          float* scale, float* shift) {
+  __shared__ double s_s[512];
+  __shared__ double s_q[512];
+  const int b = blockIdx.x, C = C1 + C2;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float* st = (c < C1) ? st1 + (size_t)(b * C1 + c) * nsub1 * 2 : st2 + (size_t)(b * C2 + (c - C1)) * nsub2 * 2;
+    const int n = (c < C1) ? nsub1 : nsub2;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < n; ++k) { s += (double)st[2 * k]; q += (double)st[2 * k + 1]; }
+    s_s[c] = s; s_q[c] = q;
+  }
+  __syncthreads();
   const int cpg = C / G;
   for (int c = threadIdx.x; c < C; c += 256) {
     const int g = c / cpg;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < cpg; ++k) {
-      s += (double)stats[((size_t)b * C + g * cpg + k) * 2 + 0];
-      q += (double)stats[((size_t)b * C + g * cpg + k) * 2 + 1];
-    }
+    for (int k = 0; k < cpg; ++k) { s += s_s[g * cpg + k]; q += s_q[g * cpg + k]; }
     const double n = (double)cpg * (double)HW;
     const double mean = s / n;
     double var = q / n - mean * mean;
