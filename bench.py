@@ -36,9 +36,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=4.0)
-    ap.add_argument("--sampler", choices=("pc", "ode"), default="pc")
-    ap.add_argument("--N", type=int, default=30)
-    ap.add_argument("--snr", type=float, default=0.5)
+    ap.add_argument("--workload", choices=("pc16k", "ode16k", "pc48k"), default="pc16k",
+                    help="BASELINE.json configs[1] (default, the headline), configs[2] (fixed-step PF-ODE) or configs[3] (48 kHz)")
+    ap.add_argument("--sampler", choices=("pc", "ode"), default=None)
+    ap.add_argument("--N", type=int, default=None)
+    ap.add_argument("--snr", type=float, default=None)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -103,6 +105,18 @@ def cpu_baseline(state, n_evals, N, snr, frames=128):
 
 def main():
     a = parse()
+    wl = {"pc16k": dict(backbone="ncsnpp", sr=16000, sampler="pc", N=30, snr=0.5, batch=32, sde=dict(theta=1.5, sigma_min=0.05, sigma_max=0.5),
+                        front=dict(), pad="zero_pad", F=256, flop=FLOP_PER_EVAL, cfg="configs[1]"),
+          "ode16k": dict(backbone="ncsnpp", sr=16000, sampler="ode", N=30, snr=0.5, batch=32, sde=dict(theta=1.5, sigma_min=0.05, sigma_max=0.5),
+                         front=dict(), pad="zero_pad", F=256, flop=FLOP_PER_EVAL, cfg="configs[2]"),
+          "pc48k": dict(backbone="ncsnpp_48k", sr=48000, sampler="pc", N=50, snr=0.33, batch=16, sde=dict(theta=2.0, sigma_min=0.1, sigma_max=1.0),
+                        front=dict(n_fft=1534, hop_length=384, spec_factor=0.065, spec_abs_exponent=0.667), pad="reflection", F=768,
+                        flop=3.187556e12, cfg="configs[3]")}[a.workload]
+    a.sampler = a.sampler or wl["sampler"]
+    a.N = a.N or wl["N"]
+    a.snr = a.snr if a.snr is not None else wl["snr"]
+    if a.batch == 32 and wl["batch"] != 32:
+        a.batch = wl["batch"]
     import torch
     import torch.distributed as dist
     from sgmse_amd import _lib
@@ -121,9 +135,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     _lib.load_library()
 
-    L = int(a.seconds * 16000)
+    L = int(a.seconds * wl["sr"])
     torch.manual_seed(0)
-    model = ScoreModel("ncsnpp", "ouve", theta=1.5, sigma_min=0.05, sigma_max=0.5, N=a.N)   # 65.6 M params, random init
+    model = ScoreModel(wl["backbone"], "ouve", N=a.N, sr=wl["sr"], **wl["sde"], **wl["front"])   # full-size network, random init
     model.to(dev).eval()
     bcast_ms = None
     if world > 1:
@@ -137,7 +151,8 @@ def main():
     y = torch.randn(a.batch, L, generator=g).to(dev)          # resident in HBM before the timed region
 
     def step(i):
-        x_hat, nfe = model.enhance_batch(y, N=a.N, snr=a.snr, sampler_type=a.sampler, seed=17 + i, use_graph=not a.no_graph)
+        x_hat, nfe = model.enhance_batch(y, N=a.N, snr=a.snr, sampler_type=a.sampler, seed=17 + i, use_graph=not a.no_graph,
+                                         pad_mode=wl["pad"])
         return x_hat, nfe
 
     def fence():
@@ -163,16 +178,20 @@ def main():
     out = None
     if rank == 0:
         utts = world * a.batch * a.steps
-        T = ((L // 128 + 1) + 63) // 64 * 64
-        flop_eval = FLOP_PER_EVAL * (T / 512.0)
+        hop = wl["front"].get("hop_length", 128)
+        T = ((L // hop + 1) + 63) // 64 * 64
+        flop_eval = wl["flop"] * (T / 512.0)
         out = {
-            "metric": "utterances/sec, SGMSE+ NCSN++ PC N=30 (reverse_diffusion + ALD, 60 NFE), 16 kHz 4 s utterances",
+            "metric": ("utterances/sec, SGMSE+ NCSN++ PC N=30 (reverse_diffusion + ALD, 60 NFE), 16 kHz 4 s utterances" if a.workload == "pc16k"
+                       else f"utterances/sec, {wl['backbone']} {a.sampler.upper()} N={a.N}, {wl['sr'] // 1000} kHz {a.seconds:g} s utterances"),
             "value": utts / elapsed, "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (N(0,1) waveforms, random-init weights of the full architecture)",
-            "config": {"workload": f"BASELINE configs[1]: NCSN++ (65.6M params) {a.sampler.upper()} sampler N={a.N}, "
-                                   f"batch={a.batch} x {a.seconds:g} s @16 kHz per GPU, hipGraph-captured step",
-                       "batch_per_gpu": a.batch, "F": 256, "T": T, "nfe": nfe, "sampler": a.sampler, "snr": a.snr,
+            "config": {"workload": f"BASELINE {wl['cfg']}: {wl['backbone']} ({model.dnn.engine(dev).param_count() / 1e6:.1f}M params) "
+                                   f"{a.sampler.upper()} sampler N={a.N}, batch={a.batch} x {a.seconds:g} s @{wl['sr'] // 1000} kHz per GPU, "
+                                   f"hipGraph-captured step",
+                       "batch_per_gpu": a.batch, "F": wl["F"], "T": T, "nfe": nfe, "sampler": a.sampler, "snr": a.snr,
+                       "arena_gb": model.dnn.engine(dev).arena_bytes() / 1e9,
                        "parallelism": f"utterance-sharded x{world} (weights broadcast once over RCCL)"},
             "rtf": elapsed / (utts * a.seconds),
             "path_tflops": a.batch * a.steps * nfe * flop_eval / elapsed / 1e12,
@@ -181,7 +200,7 @@ def main():
         if bcast_ms is not None:
             out["weight_broadcast_ms"] = bcast_ms
         if not a.no_profile:
-            Y = torch.randn(a.batch, 2, 256, T, dtype=torch.complex64, device=dev) * 0.3
+            Y = torch.randn(a.batch, 2, wl["F"], T, dtype=torch.complex64, device=dev) * 0.3
             tt = torch.full((a.batch,), 0.5, device=dev)
             ctx = model.dnn.engine(dev)
             prof, _ = ctx.profile_forward(Y, tt)
@@ -199,7 +218,7 @@ def main():
                 classes[k] = {"ms": round(v["ms"], 3), "launches": v["launches"],
                               ("tflops" if v["unit"] == "flop" else "gbps"): rate / (1e12 if v["unit"] == "flop" else 1e9)}
             out["kernel_classes_one_eval"] = classes
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and a.workload == "pc16k":
             out["cpu_baseline"] = cpu_baseline(model.dnn.state_dict(), a.cpu_evals, a.N, a.snr)
         print(json.dumps(out), flush=True)
     if world > 1:

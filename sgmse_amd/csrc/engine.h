@@ -229,6 +229,8 @@ struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; float* st = nullptr
 struct ConvW {            // one convolution's parameters on the device
   const float* oihw = nullptr;   // [cout][cin][ks][ks] (for NIN: transposed copy)
   const float* packed = nullptr; // MFMA layout (null if the shape is not MFMA-eligible)
+  const float* packed32 = nullptr; // second MFMA layout with 32-channel output tiles: 4x more workgroups for launches that
+                                   // would otherwise leave most CUs idle (the 16x32 ... 4x8 levels of the U-Net)
   const float* bias = nullptr;
   int ks = 1, cin = 0, cout = 0, co_t = 0;
 };
@@ -438,7 +440,7 @@ class Engine {
   }
 
   void op_fir(const float* x, float* out, int BC, int H, int W, int up) {
-    FirArgs fa{x, out, nullptr, nullptr, 0, BC, H, W};
+    FirArgs fa{x, out, nullptr, nullptr, 0, BC, H, W, nullptr};
     if (up) DRT_LAUNCH(fir_up2_kernel, dim3((H * W + 255) / 256, BC), dim3(256), stream_, fa);
     else DRT_LAUNCH(fir_down2_kernel, dim3(((H / 2) * (W / 2) + 255) / 256, BC), dim3(256), stream_, fa);
     check_launch();
@@ -587,6 +589,13 @@ class Engine {
       pa.cout = cout; pa.co_t = pl.co_t; pa.dst = pk; pa.total = ne;
       DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, pa);
       c.packed = pk;
+      if (pl.co_t > 32 && ks == 3) {
+        const size_t ne32 = packed_weight_elems(ks, cin, cout, 32);
+        float* pk32 = static_cast<float*>(dev_alloc(ne32 * 4));
+        PackArgs pb = pa; pb.co_t = 32; pb.dst = pk32; pb.total = ne32;
+        DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne32 + 255) / 256)), dim3(256), stream_, pb);
+        c.packed32 = pk32;
+      }
     }
     return c;
   }
@@ -762,8 +771,15 @@ class Engine {
     Tensor o = new_tensor(w.cout, a.H, a.W);
     const int kc_ = (w.ks == 3) ? 8 : 32;
     const bool use_mfma = w.packed && (b == nullptr || a.C % kc_ == 0);
+    // tile choice: the wide (128/64-channel) tile unless its grid would leave most of the 256 CUs x 2 slots empty
+    int co_t = w.co_t;
+    const int rows_ = a.H >= 8 ? 8 : 4;
+    if (use_mfma && w.packed32) {
+      const long nblk = (long)B_ * ((a.H + rows_ - 1) / rows_) * ((a.W + 31) / 32) * ((w.cout + w.co_t - 1) / w.co_t);
+      if (nblk < 384) co_t = 32;
+    }
     if (emit_stats && use_mfma && fuse_gn_stats_) {
-      o.nsub = conv_plan_nsub(w.co_t, a.H >= 8 ? 8 : 4, a.H, a.W);
+      o.nsub = conv_plan_nsub(co_t, rows_, a.H, a.W);
       o.st = arena_.alloc((size_t)B_ * w.cout * o.nsub * 2);
     }
     if (dry_) return o;
@@ -777,10 +793,10 @@ class Engine {
     tock();
     const double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
     if (use_mfma) {
-      ConvPlan pl{w.co_t, a.H >= 8 ? 8 : 4, true};
-      ca.w = w.packed;
+      ConvPlan pl{co_t, rows_, true};
+      ca.w = (co_t == w.co_t) ? w.packed : w.packed32;
       launch_conv_mfma(ca, w.ks, pl, stream_);
-      tick(w.ks == 3 ? ((w.co_t == 128 && pl.rows == 8) ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
+      tick(w.ks == 3 ? ((co_t == 128 && pl.rows == 8) ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else {
       ca.w = w.oihw;
       launch_conv_direct(ca, w.ks, stream_);
@@ -789,14 +805,16 @@ class Engine {
     return o;
   }
 
-  Tensor fir(const Tensor& a, bool up, const Xform& xf) {
+  // FIR x2 / /2 of `a` through the fused producer `xf`; with `raw` also FIR(a) itself from the same pass
+  Tensor fir(const Tensor& a, bool up, const Xform& xf, Tensor* raw = nullptr) {
     Tensor o = up ? new_tensor(a.C, a.H * 2, a.W * 2) : new_tensor(a.C, a.H / 2, a.W / 2);
+    if (raw) *raw = up ? new_tensor(a.C, a.H * 2, a.W * 2) : new_tensor(a.C, a.H / 2, a.W / 2);
     if (dry_) return o;
-    FirArgs fa{a.p, o.p, xf.scale, xf.shift, xf.act, B_ * a.C, a.H, a.W};
+    FirArgs fa{a.p, o.p, xf.scale, xf.shift, xf.act, B_ * a.C, a.H, a.W, raw ? raw->p : nullptr};
     tock();
     if (up) DRT_LAUNCH(fir_up2_kernel, dim3((a.H * a.W + 255) / 256, B_ * a.C), dim3(256), stream_, fa);
     else DRT_LAUNCH(fir_down2_kernel, dim3(((a.H / 2) * (a.W / 2) + 255) / 256, B_ * a.C), dim3(256), stream_, fa);
-    tick(TC_FIR, 4.0 * B_ * (double)a.C * (a.H * a.W + (double)o.H * o.W));
+    tick(TC_FIR, 4.0 * B_ * (double)a.C * (a.H * a.W + (raw ? 2.0 : 1.0) * o.H * o.W));
     return o;
   }
 
@@ -811,8 +829,7 @@ class Engine {
     bool have_xs = false;
     if (m.up || m.down) {
       SG_REQUIRE(b == nullptr, "resample block with concat input");
-      Tensor hr = fir(a, m.up, x0);
-      xs = fir(a, m.up, Xform{});
+      Tensor hr = fir(a, m.up, x0, &xs);
       have_xs = true;
       h = conv(r.c0, hr, nullptr, Xform{}, nullptr, temb, nullptr, 1.f, ctl, true);
       drop(hr);

@@ -39,6 +39,9 @@ struct ConvArgs {
   // {sum, sum of squares}; sub-tile = (tile index in the image) * WP + (pixel-wave index).  Deterministic (no atomics).
   float* stats_out;
   int stats_nsub;
+  // Start-up stagger (units of s_sleep 127 ~ 8k cycles) applied to the workgroups that fill the second residency slot
+  // of each CU: identical workgroups otherwise run their staging / prologue / epilogue phases in lock-step on both slots.
+  int stagger;
 };
 
 // SiLU x*sigmoid(x) (nn.SiLU, reference layers.py:38-39) on the hardware exp2/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each,
@@ -113,6 +116,11 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
   const int H = p.H, W = p.W;
   const bool xform = p.in_scale != nullptr;
 
+  if (p.stagger > 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+    if (lin >= 256u && lin < 512u)
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   // fused producer coefficients; identity when there is none, so the staging code below is branch-free
   for (int c = threadIdx.x; c < Cin; c += NT) {
     s_sc[c] = xform ? p.in_scale[b * Cin + c] : 1.f;
@@ -526,6 +534,9 @@ inline void pack_conv_weights(const float* src, float* dst, int ks, int cin, int
 //   MFMA waves | 10 = 8 + operand prefetch | +256 scalar input staging.  (iglp_opt(1) crashes hipcc 7.2; iglp_opt(0) and a
 //   one-workgroup-per-CU register target measured no better, see DESIGN.md.)
 // Variants other than the default are compiled for the 128x256 tiles only.
+#ifndef SGMSE_CONV_DEFAULT_STAGGER
+#define SGMSE_CONV_DEFAULT_STAGGER 0
+#endif
 #ifndef SGMSE_CONV_DEFAULT_VARIANT
 #define SGMSE_CONV_DEFAULT_VARIANT 4
 #endif
@@ -556,9 +567,17 @@ inline void launch_conv_mfma_v(const ConvArgs& a, drt::stream_t st, int variant)
 }
 
 // variant bit 8 (256): scalar (element-wise) input staging even when the row length allows float4 staging
+inline int conv_stagger() {
+  static int v = [] { const char* e = getenv("SGMSE_CONV_STAGGER"); return e ? atoi(e) : SGMSE_CONV_DEFAULT_STAGGER; }();
+  return v;
+}
+
 template <int KS, int WC, int FC, int FP>
-inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant = -1) {
+inline void launch_conv_mfma_t(const ConvArgs& a_in, drt::stream_t st, int variant = -1) {
   if (variant < 0) variant = conv_variant();
+  ConvArgs a = a_in;
+  if (variant & 1024) { a.stagger = (variant >> 11) & 31; variant &= 1023; }   // microbench: stagger in bits 11..15
+  else a.stagger = conv_stagger();
   const bool vec = (a.W % 4 == 0) && !(variant & 256) && a.src1 != nullptr &&
                    (reinterpret_cast<uintptr_t>(a.src1) % 16 == 0) && (a.src2 == nullptr || reinterpret_cast<uintptr_t>(a.src2) % 16 == 0);
   if (vec) launch_conv_mfma_v<KS, WC, FC, FP, 1>(a, st, variant & 255);

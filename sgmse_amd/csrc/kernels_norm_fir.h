@@ -104,15 +104,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* src1, const 
 
 struct FirArgs {
   const float* src; float* out;
-  const float* in_scale; const float* in_shift;  // [B*C] or null
+  const float* in_scale; const float* in_shift;  // [B*C] or null: out = FIR(act(x*scale+shift)), zero padding after it
   int in_act;
-  int BC, H, W;  // input plane geometry
+  int BC, H, W;    // input plane geometry
+  float* out_raw;  // optional second result FIR(x) of the same input (the ResBlock shortcut branch, layerspp.py:247-248,
+                   // 254-255 resamples both h = act(GN(x)) and x): one pass over x feeds both
 };
 
-__device__ __forceinline__ float fir_fetch(const FirArgs& p, const float* plane, int y, int x, float a, float s) {
-  if (y < 0 || y >= p.H || x < 0 || x >= p.W) return 0.f;
-  float v = plane[y * p.W + x];
-  if (p.in_scale) { v = v * a + s; if (p.in_act) v = silu_f(v); }
+// raw value (0 outside the image) and, through *xv, its fused-producer image (also 0 outside)
+__device__ __forceinline__ float fir_fetch(const FirArgs& p, const float* plane, int y, int x, float a, float s, float* xv) {
+  if (y < 0 || y >= p.H || x < 0 || x >= p.W) { *xv = 0.f; return 0.f; }
+  const float v = plane[y * p.W + x];
+  float t = v;
+  if (p.in_scale) { t = v * a + s; if (p.in_act) t = silu_f(t); }
+  *xv = t;
   return v;
 }
 
@@ -127,19 +132,37 @@ __global__ __launch_bounds__(256) void fir_down2_kernel(FirArgs p) {
   float a = 1.f, s = 0.f;
   if (p.in_scale) { a = p.in_scale[bc]; s = p.in_shift[bc]; }
   const float k[4] = {0.125f, 0.375f, 0.375f, 0.125f};
-  float acc = 0.f;
+  float acc = 0.f, acc_raw = 0.f;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    float row = 0.f;
+    float row = 0.f, row_raw = 0.f;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) row += k[v] * fir_fetch(p, plane, 2 * i + u - 1, 2 * j + v - 1, a, s);
+    for (int v = 0; v < 4; ++v) {
+      float t;
+      const float r = fir_fetch(p, plane, 2 * i + u - 1, 2 * j + v - 1, a, s, &t);
+      row += k[v] * t;
+      row_raw += k[v] * r;
+    }
     acc += k[u] * row;
+    acc_raw += k[u] * row_raw;
   }
   p.out[(size_t)bc * Ho * Wo + o] = acc;
+  if (p.out_raw) p.out_raw[(size_t)bc * Ho * Wo + o] = acc_raw;
 }
 
 // FIR x2 (polyphase): out[2m] = (x[m-1] + 3x[m])/4, out[2m+1] = (3x[m] + x[m+1])/4 per axis.
 // One thread per input pixel -> 2x2 outputs.  grid = (ceil(H*W/256), BC)
+__device__ __forceinline__ void fir_up2_emit(const float (&v)[3][3], float* out, int Wo) {
+  float he[3], ho[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    he[u] = 0.25f * v[u][0] + 0.75f * v[u][1];
+    ho[u] = 0.75f * v[u][1] + 0.25f * v[u][2];
+  }
+  *reinterpret_cast<float2*>(out) = make_float2(0.25f * he[0] + 0.75f * he[1], 0.25f * ho[0] + 0.75f * ho[1]);
+  *reinterpret_cast<float2*>(out + Wo) = make_float2(0.75f * he[1] + 0.25f * he[2], 0.75f * ho[1] + 0.25f * ho[2]);
+}
+
 __global__ __launch_bounds__(256) void fir_up2_kernel(FirArgs p) {
   const int H = p.H, W = p.W;
   const int o = blockIdx.x * 256 + threadIdx.x;
@@ -149,24 +172,15 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(FirArgs p) {
   const float* plane = p.src + (size_t)bc * H * W;
   float a = 1.f, s = 0.f;
   if (p.in_scale) { a = p.in_scale[bc]; s = p.in_shift[bc]; }
-  float v[3][3];
+  float v[3][3], vr[3][3];
 #pragma unroll
   for (int u = 0; u < 3; ++u)
 #pragma unroll
-    for (int w = 0; w < 3; ++w) v[u][w] = fir_fetch(p, plane, i + u - 1, j + w - 1, a, s);
-  // horizontal pass for the three rows
-  float he[3], ho[3];
-#pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    he[u] = 0.25f * v[u][0] + 0.75f * v[u][1];
-    ho[u] = 0.75f * v[u][1] + 0.25f * v[u][2];
-  }
+    for (int w = 0; w < 3; ++w) vr[u][w] = fir_fetch(p, plane, i + u - 1, j + w - 1, a, s, &v[u][w]);
   const int Wo = 2 * W;
-  float* out = p.out + (size_t)bc * 4 * H * W + (size_t)(2 * i) * Wo + 2 * j;
-  float2 r0 = make_float2(0.25f * he[0] + 0.75f * he[1], 0.25f * ho[0] + 0.75f * ho[1]);
-  float2 r1 = make_float2(0.75f * he[1] + 0.25f * he[2], 0.75f * ho[1] + 0.25f * ho[2]);
-  *reinterpret_cast<float2*>(out) = r0;
-  *reinterpret_cast<float2*>(out + Wo) = r1;
+  const size_t off = (size_t)bc * 4 * H * W + (size_t)(2 * i) * Wo + 2 * j;
+  fir_up2_emit(v, p.out + off, Wo);
+  if (p.out_raw) fir_up2_emit(vr, p.out_raw + off, Wo);
 }
 
 // Generic upfirdn2d (reference op/upfirdn2d.py:162-203 semantics): zero-insert by `up`, pad/crop, correlate with the

@@ -58,6 +58,7 @@ static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __expf(x) expf(x)
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sgmse_amd import _lib
 
-VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,4,8,9,10").split(",")]
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "4,3076,5124,9220,17412").split(",")]
 SHAPES = [  # ks, B, Cin, Cout, H, W
     (3, 8, 128, 128, 256, 512),
     (3, 8, 256, 128, 256, 512),

@@ -25,8 +25,13 @@ d=json.loads(open('gpurun_out/bench_v$v.log').read().strip().splitlines()[-1]); 
 if has hbm; then
   echo "== HBM traffic (FETCH_SIZE / WRITE_SIZE passes over the bench command)"
   rm -rf gpurun_out/hbm
-  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/hbm/fetch -o p -- python bench.py --steps 1 --warmup 0 --batch ${PROF_BATCH:-32} --no-cpu-baseline --no-profile > gpurun_out/hbm_fetch.log 2>&1; echo "fetch rc=$?"
-  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/hbm/write -o p -- python bench.py --steps 1 --warmup 0 --batch ${PROF_BATCH:-32} --no-cpu-baseline --no-profile > gpurun_out/hbm_write.log 2>&1; echo "write rc=$?"
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/hbm/fetch -o p -- python bench.py --steps 1 --warmup 0 --batch ${PROF_BATCH:-32} --no-cpu-baseline --no-profile --no-graph > gpurun_out/hbm_fetch.log 2>&1; echo "fetch rc=$?"
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/hbm/write -o p -- python bench.py --steps 1 --warmup 0 --batch ${PROF_BATCH:-32} --no-cpu-baseline --no-profile --no-graph > gpurun_out/hbm_write.log 2>&1; echo "write rc=$?"
+  if [ -z "$(find gpurun_out/hbm/fetch -name '*counter_collection.csv' 2>/dev/null)" ]; then
+    echo "PMC over the bench command failed; falling back to the conv micro-benchmark (default variant only)"
+    VARIANTS=-1 ROUNDS=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/hbm/fetch -o p -- python tools/conv_microbench.py > gpurun_out/hbm_fetch.log 2>&1
+    VARIANTS=-1 ROUNDS=1 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/hbm/write -o p -- python tools/conv_microbench.py > gpurun_out/hbm_write.log 2>&1
+  fi
   python tools/summarize_hbm.py gpurun_out/hbm/fetch gpurun_out/hbm/write > gpurun_out/hbm_traffic.json; head -c 1500 gpurun_out/hbm_traffic.json
   find gpurun_out/hbm -name "*.csv" -size +20M -delete
 fi
