@@ -11,10 +11,18 @@
 //   a 3x3 tap is an immediate LDS offset, so there is no im2col.  D's lane -> column map puts 32 consecutive
 //   pixels on 32 consecutive lanes, so the epilogue (bias, time-embedding bias, residual, 1/sqrt2) stores and
 //   residual loads are 128-byte coalesced rows of the NCHW tensor.
-//   Optional fused producer: GroupNorm affine (+SiLU) applied while the tile is written to LDS
-//   (layerspp.py:243,264: act(GroupNorm(x)) feeding Conv_0 / Conv_1), zero padding applied after it.
-// conv_direct: VALU direct convolution for the thin layers (4->C, C->4) and any shape the MFMA kernel does not
-//   cover; same fused producer/epilogue.
+//   Fused producer: GroupNorm affine (+SiLU) applied while the tile is written to LDS (layerspp.py:243,264:
+//   act(GroupNorm(x)) feeding Conv_0 / Conv_1), zero padding applied after it.
+//   Fused consumer: per-channel {sum, sum of squares} of the stored output for the NEXT GroupNorm, reduced with
+//   wave shuffles and written as deterministic per-tile partials (no atomics).
+// conv_direct: VALU direct convolution for the thin 4->C layers and any shape the MFMA kernel does not cover;
+//   same fused producer/epilogue.
+//
+// Structure measured on MI355X (profiles/r01_conv_microbench_*.txt, r01_pmc_conv_microbench.json): 128 co x 256 px
+// tile, 8-channel K-stages, next stage prefetched into registers during the MFMAs, two workgroups per CU.  Tried and
+// rejected (slower or equal): one workgroup per CU with a 512-register budget (-10 %), two half-size LDS stages with one
+// barrier per stage (-8 %, spills), 4 MFMA waves + 4 staging waves per workgroup (-17 %: one workgroup per CU exposes
+// every prologue/epilogue), iglp_opt(0) / s_setprio (0 %), start-up stagger of the second residency slot (0 %).
 #pragma once
 #include <sgmse_devrt.h>
 #include <type_traits>
@@ -39,9 +47,6 @@ struct ConvArgs {
   // {sum, sum of squares}; sub-tile = (tile index in the image) * WP + (pixel-wave index).  Deterministic (no atomics).
   float* stats_out;
   int stats_nsub;
-  // Start-up stagger (units of s_sleep 127 ~ 8k cycles) applied to the workgroups that fill the second residency slot
-  // of each CU: identical workgroups otherwise run their staging / prologue / epilogue phases in lock-step on both slots.
-  int stagger;
 };
 
 // SiLU x*sigmoid(x) (nn.SiLU, reference layers.py:38-39) on the hardware exp2/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each,
@@ -50,14 +55,12 @@ struct ConvArgs {
 __device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
 __device__ __forceinline__ float silu_precise_f(float v) { return v / (1.0f + expf(-v)); }   // time-embedding MLP (tiny)
 
-template <int KS, int WC, int FC, int FP, int DB = 0, int VEC = 0>
+template <int KS, int WC, int FC, int FP, int VEC = 0>
 struct ConvTile {
   static constexpr int WP = 4 / WC;                 // waves along pixels
   static constexpr int CO_T = WC * FC * 32;         // output channels per workgroup
   static constexpr int ROWS = WP * FP;              // image rows per workgroup (each pixel fragment = 32 px of a row)
-  static constexpr int KC = (KS == 3) ? 8 : 32;     // input-channel granularity of the layer (Cin % KC == 0)
-  static constexpr int NBUF = DB ? 2 : 1;           // LDS stages
-  static constexpr int KCH = KC / NBUF;             // input channels per LDS stage
+  static constexpr int KC = (KS == 3) ? 8 : 32;     // input channels per LDS stage (Cin % KC == 0)
   static constexpr int HALO = KS / 2;
   // LDS row: scalar staging packs [halo | 32 px | halo] (stride 34 / 32); vector staging keeps the 32 interior pixels
   // 16-byte aligned at column 4 with the halo columns at 3 and 36 (stride 40) so they can be written as b128
@@ -65,45 +68,30 @@ struct ConvTile {
   static constexpr int XOFF = (VEC && HALO) ? 3 : 0;   // column of the left-most tap of pixel 0
   static constexpr int TROWS = ROWS + 2 * HALO;
   static constexpr int PLANE = TROWS * RS;
-  static constexpr int NVI = KCH * TROWS * 8;          // float4 items per stage (vector staging)
-  static constexpr int NV = (NVI + 255) / 256;
-  static constexpr int NHI = KCH * TROWS * 2 * HALO;   // halo scalars per stage (vector staging)
   static constexpr int TAPS = KS * KS;
-  static constexpr int IN_ELEMS = KCH * PLANE;
-  static constexpr int W_ELEMS = KCH * TAPS * CO_T;
-  static constexpr int NI = (IN_ELEMS + 255) / 256;
+  static constexpr int IN_ELEMS = KC * PLANE;
+  static constexpr int W_ELEMS = KC * TAPS * CO_T;
+  static constexpr int NI = (IN_ELEMS + 255) / 256;    // scalar staging: elements per thread
+  static constexpr int NVI = KC * TROWS * 8;           // vector staging: float4 items per stage
+  static constexpr int NV = (NVI + 255) / 256;
+  static constexpr int NHI = KC * TROWS * 2 * HALO;    // vector staging: halo scalars per stage (<= 256)
   static constexpr int NW4 = (W_ELEMS / 4 + 255) / 256;
 };
 
-// DB = 0: one LDS stage of KC channels, two barriers per stage, next stage prefetched into registers during the MFMAs.
-// DB = 1: two LDS stages of KC/2 channels (same LDS footprint): the stage after next is fetched into registers and the
-//         next stage written to the idle LDS buffer inside the same basic block as the current stage's MFMAs (one
-//         barrier per stage), so a wave's own staging work sits in the shadow of its own MFMAs.
-// SCHED: 0 compiler default, 1 = __builtin_amdgcn_iglp_opt(0) on the MFMA block, 3 = s_setprio(1) around it,
-//        4 = explicit operand prefetch one k-step ahead, order pinned with sched_group_barrier.
-// WS = 1: wave-specialised workgroup of 512 threads (requires DB): waves 0-3 only read LDS and issue MFMAs, waves 4-7 only
-//         stage (global loads, fused GroupNorm/SiLU, LDS writes) the next K-stage into the idle buffer.  The matrix pipe of
-//         every SIMD is then fed by a wave that never leaves its MFMA stream, while its partner wave on the same SIMD uses the
-//         VALU/LDS/VMEM issue slots in between (the two blocks-per-CU arrangement of WS = 0 runs its staging phases in
-//         lock-step and leaves the pipe ~20 % idle: profiles/r01_pmc_conv_microbench.json).
-template <int KS, int WC, int FC, int FP, int MINW, int DB, int SCHED, int VEC, int WS = 0>
-__global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArgs p) {
-  static_assert(!WS || DB, "wave specialisation needs the two-stage LDS layout");
-  using T = ConvTile<KS, WC, FC, FP, DB, VEC>;
-  constexpr int CO_T = T::CO_T, ROWS = T::ROWS, KCH = T::KCH, HALO = T::HALO, RS = T::RS, PLANE = T::PLANE,
-                TAPS = T::TAPS, NI = VEC ? 1 : T::NI, NW4 = T::NW4, NBUF = T::NBUF, NV = VEC ? T::NV : 1,
-                TROWS = T::TROWS;
-  // the two stages are separate objects so that the compiler knows LDS writes of one never alias reads of the other
-  __shared__ float s_in0[T::IN_ELEMS];
-  __shared__ float s_w0[T::W_ELEMS];
-  __shared__ float s_in1[DB ? T::IN_ELEMS : 4];
-  __shared__ float s_w1[DB ? T::W_ELEMS : 4];
+// PREF = 1: the LDS operand reads of k-step s+1 are issued before the MFMAs of k-step s (order pinned with
+//           sched_group_barrier), so a wave does not park on lgkmcnt between MFMA groups.  PREF = 0: compiler order.
+// VEC  = 1: float4 input staging (needs W % 4 == 0 and 16-byte aligned sources); 0: element-wise staging.
+template <int KS, int WC, int FC, int FP, int PREF, int VEC>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
+  using T = ConvTile<KS, WC, FC, FP, VEC>;
+  constexpr int CO_T = T::CO_T, ROWS = T::ROWS, KC = T::KC, HALO = T::HALO, RS = T::RS, PLANE = T::PLANE,
+                TAPS = T::TAPS, NI = VEC ? 1 : T::NI, NW4 = T::NW4, NV = VEC ? T::NV : 1, TROWS = T::TROWS;
+  __shared__ float s_in[T::IN_ELEMS];
+  __shared__ float s_w[T::W_ELEMS];
   __shared__ float s_sc[512];
   __shared__ float s_sh[512];
 
-  constexpr int NT = WS ? 512 : 256;
-  const bool producer = WS && threadIdx.x >= 256;
-  const int tid = threadIdx.x & 255;   // staging index (producers) / MFMA index (consumers)
+  const int tid = threadIdx.x;
   const int Cin = p.C1 + p.C2;
   const int tiles_x = (p.W + 31) >> 5;
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
@@ -116,13 +104,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
   const int H = p.H, W = p.W;
   const bool xform = p.in_scale != nullptr;
 
-  if (p.stagger > 0) {
-    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-    if (lin >= 256u && lin < 512u)
-      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   // fused producer coefficients; identity when there is none, so the staging code below is branch-free
-  for (int c = threadIdx.x; c < Cin; c += NT) {
+  for (int c = tid; c < Cin; c += 256) {
     s_sc[c] = xform ? p.in_scale[b * Cin + c] : 1.f;
     s_sh[c] = xform ? p.in_shift[b * Cin + c] : 0.f;
   }
@@ -153,7 +136,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
   const float* wbase = p.w + (size_t)co_blk * Cin * TAPS * CO_T;
   const size_t HW = (size_t)H * W;
 
-  // Per-thread staging coordinates do not depend on the chunk.  Threads past the end of the item list re-stage the last
+  // Per-thread staging coordinates do not depend on the stage.  Threads past the end of the item list re-stage the last
   // item (same address, same value), which keeps every load and LDS store unconditional (no divergent branches).
   if constexpr (!VEC) {
 #pragma unroll
@@ -170,7 +153,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
       goff[i] = ok ? gy * W + gx : 0;
     }
   } else {
-    // vector staging (W % 4 == 0): the 32 interior pixels of a tile row are 8 aligned float4; halo columns are scalars
+    // the 32 interior pixels of a tile row are 8 aligned float4 (all-or-nothing inside the image since W % 4 == 0);
+    // the halo columns are scalars
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int it = tid + 256 * i;
@@ -185,7 +169,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
       loff_v[i] = c * PLANE + r * RS + (HALO ? 4 : 0) + 4 * q;
     }
     if (HALO) {
-      int it = tid < T::NHI ? tid : T::NHI - 1;
+      const int it = tid < T::NHI ? tid : T::NHI - 1;
       const int c = it / (TROWS * 2);
       const int rem = it - c * (TROWS * 2);
       const int r = rem >> 1, side = rem & 1;
@@ -201,7 +185,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
     return (cg < p.C1) ? p.src1 + (size_t)(b * p.C1 + cg) * HW : p.src2 + (size_t)(b * p.C2 + (cg - p.C1)) * HW;
   };
 
-  auto load_chunk = [&](int c0) {
+  // global -> registers (stage c0 .. c0+KC-1)
+  auto load_stage = [&](int c0) {
     if constexpr (!VEC) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -234,19 +219,18 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
     v = v * sc + sh;
     const float sv = silu_f(v);
     v = act ? sv : v;
-    return ok ? v : 0.f;
+    return ok ? v : 0.f;   // zero padding is applied after the fused producer
   };
 
-  auto store_chunk = [&](int c0, auto bufc) {
-    constexpr int BUF = decltype(bufc)::value;
-    float* din = BUF ? s_in1 : s_in0;
+  // registers -> LDS, through the fused producer
+  auto store_stage = [&](int c0) {
     if constexpr (!VEC) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         int e = tid + 256 * i;
         e = e < T::IN_ELEMS ? e : T::IN_ELEMS - 1;
         const int cg = c0 + e / PLANE;
-        din[e] = xf1(rin[i], s_sc[cg], s_sh[cg], (okmask >> i) & 1u);
+        s_in[e] = xf1(rin[i], s_sc[cg], s_sh[cg], (okmask >> i) & 1u);
       }
     } else {
 #pragma unroll
@@ -259,15 +243,15 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
         f32x4 o;
         o[0] = xf1(rv[i][0], sc, sh, ok); o[1] = xf1(rv[i][1], sc, sh, ok);
         o[2] = xf1(rv[i][2], sc, sh, ok); o[3] = xf1(rv[i][3], sc, sh, ok);
-        *reinterpret_cast<f32x4*>(din + loff_v[i]) = o;
+        *reinterpret_cast<f32x4*>(s_in + loff_v[i]) = o;
       }
       if (HALO) {
         const int it = tid < T::NHI ? tid : T::NHI - 1;
         const int cg = c0 + it / (TROWS * 2);
-        din[loff_h] = xf1(rin[0], s_sc[cg], s_sh[cg], (okmask >> 31) & 1u);
+        s_in[loff_h] = xf1(rin[0], s_sc[cg], s_sh[cg], (okmask >> 31) & 1u);
       }
     }
-    f32x4* wdst = reinterpret_cast<f32x4*>(BUF ? s_w1 : s_w0);
+    f32x4* wdst = reinterpret_cast<f32x4*>(s_w);
 #pragma unroll
     for (int i = 0; i < NW4; ++i) {
       int idx = tid + 256 * i;
@@ -276,17 +260,12 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
     }
   };
 
-  auto compute = [&](auto bufc) {
-    constexpr int BUF = decltype(bufc)::value;
-    const float* sw = (BUF ? s_w1 : s_w0) + a_off;
-    const float* si = (BUF ? s_in1 : s_in0) + b_off;
-    if (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
-    if (SCHED == 3 && !WS) __builtin_amdgcn_s_setprio(1);
-    if (SCHED == 4) {
-      // Explicit operand pipeline: the LDS reads of k-step s+1 are issued before the MFMAs of k-step s, so a wave
-      // never parks on lgkmcnt between MFMA groups (two co-resident waves otherwise reach their LDS waits in
-      // lock-step and leave the matrix pipe idle).  The sched_group_barrier template pins that order.
-      constexpr int NS = (KCH / 2) * TAPS;
+  // MFMAs of one stage: k-step = (channel pair, tap); lane (kh, l31) supplies channel 2*cp+kh
+  auto compute = [&]() {
+    const float* sw = s_w + a_off;
+    const float* si = s_in + b_off;
+    if constexpr (PREF) {
+      constexpr int NS = (KC / 2) * TAPS;
       float a[2][FC], bb[2][FP];
       auto ld = [&](int s2, int slot) {
         const int cp = s2 / TAPS, tap = s2 % TAPS, dy = tap / KS, dx = tap % KS;
@@ -308,64 +287,42 @@ __global__ __launch_bounds__(WS ? 512 : 256, MINW) void conv_mfma_kernel(ConvArg
       __builtin_amdgcn_sched_group_barrier(0x100, FC + FP, 0);
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) {
-        if (s2 + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, FC + FP, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, FC * FP, 0);
+        if (s2 + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, FC + FP, 0);   // LDS reads of k-step s2+1
+        __builtin_amdgcn_sched_group_barrier(0x008, FC * FP, 0);                    // MFMAs of k-step s2
       }
-      return;
-    }
-    constexpr int UNR = DB ? KCH / 2 : 1;
-#pragma unroll UNR
-    for (int cp = 0; cp < KCH / 2; ++cp) {
+    } else {
+#pragma unroll 1
+      for (int cp = 0; cp < KC / 2; ++cp) {
 #pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        const int dy = tap / KS, dx = tap % KS;
-        float a[FC], bb[FP];
+        for (int tap = 0; tap < TAPS; ++tap) {
+          const int dy = tap / KS, dx = tap % KS;
+          float a[FC], bb[FP];
 #pragma unroll
-        for (int i = 0; i < FC; ++i) a[i] = sw[i * 32 + (cp * 2 * TAPS + tap) * CO_T];
+          for (int i = 0; i < FC; ++i) a[i] = sw[i * 32 + (cp * 2 * TAPS + tap) * CO_T];
 #pragma unroll
-        for (int j = 0; j < FP; ++j) bb[j] = si[j * RS + cp * 2 * PLANE + dy * RS + dx];
+          for (int j = 0; j < FP; ++j) bb[j] = si[j * RS + cp * 2 * PLANE + dy * RS + dx];
 #pragma unroll
-        for (int i = 0; i < FC; ++i)
+          for (int i = 0; i < FC; ++i)
 #pragma unroll
-          for (int j = 0; j < FP; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FP; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
       }
     }
-    if (SCHED == 3 && !WS) __builtin_amdgcn_s_setprio(0);
   };
 
-  const int nchunks = Cin / KCH;
-  if (!WS || producer) load_chunk(0);
+  const int nstages = Cin / KC;
+  load_stage(0);
   __syncthreads();  // s_sc / s_sh visible
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
-  if (WS) {
-    if (producer) { store_chunk(0, B0{}); }
+  for (int ci = 0; ci < nstages; ++ci) {
+    store_stage(ci * KC);
     __syncthreads();
-    if (SCHED == 3 && !producer) __builtin_amdgcn_s_setprio(1);
-    for (int ci = 0; ci < nchunks; ci += 2) {
-      if (producer) { if (ci + 1 < nchunks) { load_chunk((ci + 1) * KCH); store_chunk((ci + 1) * KCH, B1{}); } }
-      else compute(B0{});
-      __syncthreads();
-      if (ci + 1 < nchunks) {
-        if (producer) { if (ci + 2 < nchunks) { load_chunk((ci + 2) * KCH); store_chunk((ci + 2) * KCH, B0{}); } }
-        else compute(B1{});
-        __syncthreads();
-      }
-    }
-    if (producer) return;
-  } else if (DB) {
-    store_chunk(0, B0{});  } else {
-    for (int ci = 0; ci < nchunks; ++ci) {
-      store_chunk(ci * KCH, B0{});
-      __syncthreads();
-      if (ci + 1 < nchunks) load_chunk((ci + 1) * KCH);
-      compute(B0{});
-      __syncthreads();
-    }
+    if (ci + 1 < nstages) load_stage((ci + 1) * KC);   // in flight during the MFMAs
+    compute();
+    __syncthreads();
   }
 
-  // epilogue
+  // epilogue: D[co = regs][px = lanes] -> NCHW rows
   const int x = x0 + l31;
   const float* b2 = nullptr;
   if (p.bias2) {
@@ -516,72 +473,26 @@ inline size_t packed_weight_elems(int ks, int cin, int cout, int co_t) {
   return (size_t)nblk * cin * ks * ks * co_t;
 }
 
-// dst[blk][c][tap][j] = src[blk*co_t + j][c][tap]   (zero where blk*co_t + j >= cout)
-inline void pack_conv_weights(const float* src, float* dst, int ks, int cin, int cout, int co_t) {
-  const int taps = ks * ks, nblk = (cout + co_t - 1) / co_t;
-  for (int blk = 0; blk < nblk; ++blk)
-    for (int c = 0; c < cin; ++c)
-      for (int t = 0; t < taps; ++t)
-        for (int j = 0; j < co_t; ++j) {
-          const int co = blk * co_t + j;
-          dst[(((size_t)blk * cin + c) * taps + t) * co_t + j] = co < cout ? src[((size_t)co * cin + c) * taps + t] : 0.f;
-        }
-}
-
-// Kernel variant of the MFMA convolution, chosen once per process from SGMSE_CONV_VARIANT (measurement knob):
-//   0 default | 1 double-buffered LDS stages | 4 operand prefetch pinned with sched_group_barrier | 5 = 1+4 |
-//   6 s_setprio around the MFMA block | 8 wave-specialised (4 MFMA waves + 4 staging waves) | 9 = 8 + s_setprio for the
-//   MFMA waves | 10 = 8 + operand prefetch | +256 scalar input staging.  (iglp_opt(1) crashes hipcc 7.2; iglp_opt(0) and a
-//   one-workgroup-per-CU register target measured no better, see DESIGN.md.)
-// Variants other than the default are compiled for the 128x256 tiles only.
-#ifndef SGMSE_CONV_DEFAULT_STAGGER
-#define SGMSE_CONV_DEFAULT_STAGGER 0
-#endif
-#ifndef SGMSE_CONV_DEFAULT_VARIANT
-#define SGMSE_CONV_DEFAULT_VARIANT 4
-#endif
+// Measurement knob SGMSE_CONV_VARIANT (also the `variant` argument of sgmse_bench_conv):
+//   bit 0: operand prefetch off (compiler-ordered LDS reads)   bit 1: element-wise instead of float4 input staging
 inline int conv_variant() {
-  static int v = [] { const char* e = getenv("SGMSE_CONV_VARIANT"); return e ? atoi(e) : SGMSE_CONV_DEFAULT_VARIANT; }();
-  return v;
-}
-
-template <int KS, int WC, int FC, int FP, int VEC>
-inline void launch_conv_mfma_v(const ConvArgs& a, drt::stream_t st, int variant) {
-  using T = ConvTile<KS, WC, FC, FP>;
-  const int tiles = a.B * ((a.H + T::ROWS - 1) / T::ROWS) * ((a.W + 31) / 32);
-  dim3 grid(tiles, (a.Cout + T::CO_T - 1) / T::CO_T, 1);
-  if (variant < 0) variant = conv_variant();
-  if constexpr (FC * FP == 8) {
-    switch (variant) {
-#define SGMSE_V(ID, MINW_, DB_, SCHED_) \
-      case ID: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, MINW_, DB_, SCHED_, VEC, 0>), grid, dim3(256), st, a); return;
-      SGMSE_V(1, 2, 1, 0) SGMSE_V(4, 2, 0, 4) SGMSE_V(5, 2, 1, 4) SGMSE_V(6, 2, 0, 3)
-#undef SGMSE_V
-      case 8: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 1, 0, VEC, 1>), grid, dim3(512), st, a); return;
-      case 9: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 1, 3, VEC, 1>), grid, dim3(512), st, a); return;
-      case 10: DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 1, 4, VEC, 1>), grid, dim3(512), st, a); return;
-      default: break;
-    }
-  }
-  DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 2, 0, 0, VEC, 0>), grid, dim3(256), st, a);
-}
-
-// variant bit 8 (256): scalar (element-wise) input staging even when the row length allows float4 staging
-inline int conv_stagger() {
-  static int v = [] { const char* e = getenv("SGMSE_CONV_STAGGER"); return e ? atoi(e) : SGMSE_CONV_DEFAULT_STAGGER; }();
+  static int v = [] { const char* e = getenv("SGMSE_CONV_VARIANT"); return e ? atoi(e) : 0; }();
   return v;
 }
 
 template <int KS, int WC, int FC, int FP>
-inline void launch_conv_mfma_t(const ConvArgs& a_in, drt::stream_t st, int variant = -1) {
+inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant) {
+  using T = ConvTile<KS, WC, FC, FP>;
+  const int tiles = a.B * ((a.H + T::ROWS - 1) / T::ROWS) * ((a.W + 31) / 32);
+  dim3 grid(tiles, (a.Cout + T::CO_T - 1) / T::CO_T, 1);
   if (variant < 0) variant = conv_variant();
-  ConvArgs a = a_in;
-  if (variant & 1024) { a.stagger = (variant >> 11) & 31; variant &= 1023; }   // microbench: stagger in bits 11..15
-  else a.stagger = conv_stagger();
-  const bool vec = (a.W % 4 == 0) && !(variant & 256) && a.src1 != nullptr &&
-                   (reinterpret_cast<uintptr_t>(a.src1) % 16 == 0) && (a.src2 == nullptr || reinterpret_cast<uintptr_t>(a.src2) % 16 == 0);
-  if (vec) launch_conv_mfma_v<KS, WC, FC, FP, 1>(a, st, variant & 255);
-  else launch_conv_mfma_v<KS, WC, FC, FP, 0>(a, st, variant & 255);
+  const bool vec = (a.W % 4 == 0) && !(variant & 2) && (reinterpret_cast<uintptr_t>(a.src1) % 16 == 0) &&
+                   (a.src2 == nullptr || reinterpret_cast<uintptr_t>(a.src2) % 16 == 0);
+  const bool pref = !(variant & 1);
+  if (vec && pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 1>), grid, dim3(256), st, a);
+  else if (vec) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 1>), grid, dim3(256), st, a);
+  else if (pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 0>), grid, dim3(256), st, a);
+  else DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 0>), grid, dim3(256), st, a);
 }
 
 inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1) {

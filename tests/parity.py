@@ -208,3 +208,18 @@ def check_enhance(dev, L=8000, N=2):
     assert rel_l2(x_hat, x_ref) < WAVE_TOL
     xb, nfe = m.enhance_batch(y, N=N, noise=noise)
     assert nfe == 2 * N and rel_l2(xb[0].cpu(), x_ref) < WAVE_TOL
+
+
+def check_sampler_oracle(dev, variant="ncsnpp_48k", N=2, corrector="ald", snr=0.33, F_=192, T=64, B=1, use_graph=True):
+    """PC sampler of a reduced-width model against the oracle loop with replayed noise (covers ncsnpp_48k, whose
+    output_layer / division-by-t order differs: ncsnpp_48k.py:414-421)."""
+    cfg = NO.NetCfg.for_variant(variant, nf=32)
+    sde_kw = dict(theta=2.0, sigma_min=0.1, sigma_max=1.0) if variant == "ncsnpp_48k" else {}
+    m, P = make_model(cfg, dev, **sde_kw)
+    y = synth.synth_spec(B, F_, T, seed=4)
+    so = SO.OUVE(m.sde.theta, m.sde.sigma_min, m.sde.sigma_max, N)
+    rep = SO.NoiseReplay(7)
+    ref, nfe_ref = SO.pc_sample(so, lambda a, b, c: NO.score_fn(P, cfg, a, b, c), y, rep, eps=0.03, snr=snr, corrector=corrector)
+    noise = torch.stack(rep.draws).to(dev)
+    out, nfe = m.get_pc_sampler("reverse_diffusion", corrector, y.to(dev), N=N, snr=snr, noise=noise, use_graph=use_graph)()
+    assert nfe == nfe_ref and rel_l2(out.cpu(), ref) < SAMPLER_TOL

@@ -24,6 +24,15 @@ def test_conv_direct(emu, shape):
     P.check_conv(emu, *shape, direct=True)
 
 
+def test_conv_thin_output_on_padded_mfma_tile(emu):
+    P.check_conv(emu, 1, 64, 4, 9, 33, 3, xform=True)
+    P.check_conv(emu, 2, 128, 4, 4, 8, 3, xform=True)
+
+
+def test_sampler_48k_variant_against_oracle(emu):
+    P.check_sampler_oracle(emu, "ncsnpp_48k", N=1, snr=0.33, F_=192, T=64, B=1)
+
+
 def test_conv_concat_and_fused_groupnorm_silu(emu):
     P.check_conv(emu, 2, 96, 32, 12, 36, 3, dual=64, xform=True)
     P.check_conv(emu, 1, 64, 32, 8, 8, 1, dual=32, xform=True)

@@ -19,9 +19,27 @@ pytestmark = pytest.mark.gpu
     (2, 32, 32, 16, 40, 3), (1, 64, 128, 9, 33, 3), (2, 32, 64, 4, 8, 3), (1, 96, 32, 8, 32, 1), (2, 64, 64, 5, 7, 1),
     (1, 64, 64, 3, 1, 3), (1, 32, 32, 1, 1, 1),
     (2, 128, 128, 64, 96, 3), (1, 256, 128, 32, 64, 3), (1, 512, 256, 16, 32, 3), (1, 384, 128, 24, 48, 3),
-    (1, 256, 256, 16, 32, 1), (2, 256, 768, 16, 32, 1), (1, 128, 128, 4, 8, 3)])
+    (1, 256, 256, 16, 32, 1), (2, 256, 768, 16, 32, 1), (1, 128, 128, 4, 8, 3), (2, 128, 4, 64, 96, 3), (1, 256, 4, 8, 16, 3)])
 def test_conv_mfma(hip, shape):
     P.check_conv(hip, *shape)
+
+
+def test_conv_mfma_fused_groupnorm_statistics_path(hip):
+    """Network-level check of the epilogue-fused GroupNorm statistics against the stand-alone statistics pass: the two
+    engines must agree to rounding (same network, SGMSE_FUSE_GN_STATS toggled in a child process)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import parity as P\nfrom sgmse_amd import _lib\n_lib.load_library()\n"
+            "net, _ = P.make_backbone(P.NET_CASES['fwd_nf32'], 'cuda')\nz = P.load('fwd_nf32')\n"
+            "out = net(torch.from_numpy(z['x']).cuda(), torch.from_numpy(z['t']).cuda())\n"
+            "torch.save(out.cpu(), sys.argv[1])\n") % (ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    for flag in ("1", "0"):
+        path = os.path.join("/tmp", f"gnfuse_{flag}.pt")
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, SGMSE_FUSE_GN_STATS=flag), timeout=600)
+        outs.append(torch.load(path))
+    assert rel_l2(outs[0], outs[1]) < 2e-6
 
 
 @pytest.mark.parametrize("shape", [(2, 4, 128, 32, 40, 3), (2, 128, 4, 32, 40, 3), (1, 4, 256, 16, 20, 1), (1, 24, 20, 7, 9, 3)])
@@ -68,6 +86,11 @@ def test_forward_matches_reference(hip, name):
 @pytest.mark.parametrize("tag", ["pc_N4", "pc_N30", "pnone_N6", "pfode_N6"])
 def test_samplers_match_reference(hip, tag):
     P.check_sampler_golden(hip, tag)
+
+
+def test_sampler_48k_variant_against_oracle(hip):
+    P.check_sampler_oracle(hip, "ncsnpp_48k", N=3, snr=0.33, F_=192, T=64, B=2)
+    P.check_sampler_oracle(hip, "ncsnpp", N=2, corrector="none", snr=0.5, F_=256, T=128, B=1)
 
 
 def test_sampler_graph_equals_eager(hip):

@@ -1,36 +1,55 @@
 #!/usr/bin/env python3
 """A/B of the MFMA convolution kernel variants on the dominant shapes (random operands, HIP-event timing of
-back-to-back launches; interleaved rounds, median reported)."""
+back-to-back launches; interleaved rounds, median reported).
+
+Env: VARIANTS (kernel-variant ids, see kernels_conv.h), SHAPES (indices into SHAPES below), FUSED (0,1), ROUNDS,
+CALIB=1 (also run one GroupNorm-statistics pass over a tensor of known size and record its byte count: a float4
+read stream used to calibrate FETCH_SIZE when this script runs under rocprofv3 --pmc)."""
 import json
 import os
 import statistics
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch
 from sgmse_amd import _lib
 
-VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "4,3076,5124,9220,17412").split(",")]
-SHAPES = [  # ks, B, Cin, Cout, H, W
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,1,2").split(",")]
+ALL_SHAPES = [  # ks, B, Cin, Cout, H, W
     (3, 8, 128, 128, 256, 512),
     (3, 8, 256, 128, 256, 512),
     (3, 16, 256, 256, 64, 128),
     (1, 8, 256, 128, 256, 512),
 ]
+SHAPES = [ALL_SHAPES[int(i)] for i in os.environ.get("SHAPES", "0,1,2,3").split(",")]
+FUSED = [int(v) for v in os.environ.get("FUSED", "0,1").split(",")]
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
 _lib.load_library()
 ctx = _lib.Context("cuda")
 res = {}
 for (ks, B, ci, co, H, W) in SHAPES:
     flops = 2.0 * B * co * ci * ks * ks * H * W
-    for fused in (0, 1):
+    for fused in FUSED:
         times = {v: [] for v in VARIANTS}
         for r in range(ROUNDS):
             for v in VARIANTS:
                 times[v].append(ctx.bench_conv(ks, B, ci, co, H, W, variant=v, iters=5, fused=bool(fused)))
         for v in VARIANTS:
             med = statistics.median(times[v])
-            res[f"ks{ks}_B{B}_{ci}to{co}_{H}x{W}_fused{fused}_v{v}"] = {"ms": round(med, 4), "tflops": round(flops / med / 1e9, 1),
-                                                                      "min_ms": round(min(times[v]), 4)}
+            alg = 4.0 * B * H * W * (ci + co * (2 if fused else 1)) + 4.0 * co * ci * ks * ks
+            res[f"ks{ks}_B{B}_{ci}to{co}_{H}x{W}_fused{fused}_v{v}"] = {
+                "ms": round(med, 4), "tflops": round(flops / med / 1e9, 1), "min_ms": round(min(times[v]), 4),
+                "algorithmic_bytes_per_launch": alg}
             print(f"ks={ks} B={B} {ci}->{co} {H}x{W} fused={fused} variant={v}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TFLOP/s", flush=True)
-json.dump(res, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "conv_microbench.json"), "w"), indent=1)
+out_dir = os.path.join(ROOT, "gpurun_out")
+os.makedirs(out_dir, exist_ok=True)
+if os.environ.get("CALIB") == "1":
+    from sgmse_amd import ops
+    x = torch.randn(8, 128, 256, 512, device="cuda")
+    w = torch.ones(128, device="cuda")
+    for _ in range(3):
+        ops.group_norm(x, w, w)
+    torch.cuda.synchronize()
+    res["_calibration"] = {"gn_chan_stats_kernel_read_bytes_per_launch": x.numel() * 4}
+json.dump(res, open(os.path.join(out_dir, os.environ.get("OUT", "conv_microbench.json")), "w"), indent=1)

@@ -23,17 +23,13 @@ for v in ${BENCH_VARIANTS:-}; do echo "== bench SGMSE_CONV_VARIANT=$v"; SGMSE_CO
 import json,sys
 d=json.loads(open('gpurun_out/bench_v$v.log').read().strip().splitlines()[-1]); print('variant $v', d['value'], d['roofline']['achieved'], {k:v['ms'] for k,v in d['kernel_classes_one_eval'].items()})"; done
 if has hbm; then
-  echo "== HBM traffic (FETCH_SIZE / WRITE_SIZE passes over the bench command)"
+  echo "== HBM traffic of the dominant kernel (FETCH_SIZE / WRITE_SIZE passes; rocprofv3 --pmc segfaults on the full bench command)"
   rm -rf gpurun_out/hbm
-  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/hbm/fetch -o p -- python bench.py --steps 1 --warmup 0 --batch ${PROF_BATCH:-32} --no-cpu-baseline --no-profile --no-graph > gpurun_out/hbm_fetch.log 2>&1; echo "fetch rc=$?"
-  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/hbm/write -o p -- python bench.py --steps 1 --warmup 0 --batch ${PROF_BATCH:-32} --no-cpu-baseline --no-profile --no-graph > gpurun_out/hbm_write.log 2>&1; echo "write rc=$?"
-  if [ -z "$(find gpurun_out/hbm/fetch -name '*counter_collection.csv' 2>/dev/null)" ]; then
-    echo "PMC over the bench command failed; falling back to the conv micro-benchmark (default variant only)"
-    VARIANTS=-1 ROUNDS=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/hbm/fetch -o p -- python tools/conv_microbench.py > gpurun_out/hbm_fetch.log 2>&1
-    VARIANTS=-1 ROUNDS=1 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/hbm/write -o p -- python tools/conv_microbench.py > gpurun_out/hbm_write.log 2>&1
-  fi
-  python tools/summarize_hbm.py gpurun_out/hbm/fetch gpurun_out/hbm/write > gpurun_out/hbm_traffic.json; head -c 1500 gpurun_out/hbm_traffic.json
-  find gpurun_out/hbm -name "*.csv" -size +20M -delete
+  export VARIANTS=-1 ROUNDS=1 SHAPES=0 FUSED=1 CALIB=1 OUT=hbm_microbench.json
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/hbm/fetch -o p -- python tools/conv_microbench.py > gpurun_out/hbm_fetch.log 2>&1; echo "fetch rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/hbm/write -o p -- python tools/conv_microbench.py > gpurun_out/hbm_write.log 2>&1; echo "write rc=$?"
+  unset VARIANTS ROUNDS SHAPES FUSED CALIB OUT
+  python tools/summarize_hbm.py gpurun_out/hbm/fetch gpurun_out/hbm/write gpurun_out/hbm_microbench.json > gpurun_out/hbm_traffic.json; head -c 1800 gpurun_out/hbm_traffic.json
 fi
 if has rocprof; then
   echo "== rocprofv3 kernel trace of the bench command"
