@@ -103,6 +103,23 @@ def cpu_baseline(state, n_evals, N, snr, frames=128):
             "seconds_per_eval": t_eval, "rtf": per_utt / 4.0}
 
 
+def hbm_traffic_of_dominant_kernel():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate passes, read side calibrated x2 in the same run; tools/summarize_hbm.py).  rocprofv3 --pmc segfaults on the
+    full bench command, so the counters are collected on the kernel micro-benchmark at the dominant layer shape."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")))
+    if not files:
+        return None, "no PMC profile committed"
+    d = json.load(open(files[-1]))
+    for k, v in d.items():
+        if k.startswith("void sgmse::conv_mfma_kernel<3, 2, 2, 4"):
+            alg = d.get("_algorithmic_bytes_per_launch_of_the_benchmarked_conv")
+            return v["hbm_bytes_per_launch"], (f"{os.path.basename(files[-1])}: 3x3 128->128 @256x512, B=8, fused producer+residual epilogue; "
+                                               f"algorithmic bytes of that launch = {alg:.4g}" if alg else os.path.basename(files[-1]))
+    return None, "dominant kernel not in " + os.path.basename(files[-1])
+
+
 def main():
     a = parse()
     wl = {"pc16k": dict(backbone="ncsnpp", sr=16000, sampler="pc", N=30, snr=0.5, batch=32, sde=dict(theta=1.5, sigma_min=0.05, sigma_max=0.5),
@@ -206,8 +223,9 @@ def main():
             prof, _ = ctx.profile_forward(Y, tt)
             dom = prof["conv3x3_mfma_128x256"]
             ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+            traffic, traffic_note = hbm_traffic_of_dominant_kernel()
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
+                               "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                                "kernel": "conv_mfma_kernel<3,2,2,4,*> (3x3 fp32 implicit GEMM, 128co x 256px tile)",
                                "launches_per_eval": dom["launches"],
                                "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),

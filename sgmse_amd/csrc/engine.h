@@ -771,12 +771,14 @@ class Engine {
     Tensor o = new_tensor(w.cout, a.H, a.W);
     const int kc_ = (w.ks == 3) ? 8 : 32;
     const bool use_mfma = w.packed && (b == nullptr || a.C % kc_ == 0);
-    // tile choice: the wide (128/64-channel) tile unless its grid would leave most of the 256 CUs x 2 slots empty
+    // tile choice: the wide (128/64-channel) tile, except on the coarse U-Net levels (<= 8 wide tiles per image: 16x32 and
+    // below at 4 s), where 32-channel tiles give 4x more workgroups.  Decided per IMAGE, not per batch, so that the
+    // arithmetic (incl. the order of the GroupNorm partial sums) of one utterance never depends on its batch.
     int co_t = w.co_t;
     const int rows_ = a.H >= 8 ? 8 : 4;
     if (use_mfma && w.packed32) {
-      const long nblk = (long)B_ * ((a.H + rows_ - 1) / rows_) * ((a.W + 31) / 32) * ((w.cout + w.co_t - 1) / w.co_t);
-      if (nblk < 384) co_t = 32;
+      const long per_image = (long)((a.H + rows_ - 1) / rows_) * ((a.W + 31) / 32) * ((w.cout + w.co_t - 1) / w.co_t);
+      if (per_image <= 8) co_t = 32;
     }
     if (emit_stats && use_mfma && fuse_gn_stats_) {
       o.nsub = conv_plan_nsub(co_t, rows_, a.H, a.W);
