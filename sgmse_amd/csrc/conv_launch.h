@@ -1,0 +1,70 @@
+// Launchers of the convolution kernels (tile selection happens in the engine / choose_conv_plan).
+#pragma once
+#include "kernels_conv.h"
+#include "kernels_conv_pipe.h"
+
+#ifndef SGMSE_CONV_PIPE_DEFAULT
+#define SGMSE_CONV_PIPE_DEFAULT 0
+#endif
+
+namespace sgmse {
+
+// Measurement knob SGMSE_CONV_VARIANT (also the `variant` argument of sgmse_bench_conv):
+//   bit 0: operand prefetch off (compiler-ordered LDS reads)   bit 1: element-wise instead of float4 input staging
+//   bit 2: toggle the software-pipelined kernel (kernels_conv_pipe.h) for the 128 x 256 tiles
+inline int conv_variant() {
+  static int v = [] { const char* e = getenv("SGMSE_CONV_VARIANT"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
+template <int KS, int WC, int FC, int FP>
+inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant) {
+  using T = ConvTile<KS, WC, FC, FP>;
+  const int tiles = a.B * ((a.H + T::ROWS - 1) / T::ROWS) * ((a.W + 31) / 32);
+  dim3 grid(tiles, (a.Cout + T::CO_T - 1) / T::CO_T, 1);
+  if (variant < 0) variant = conv_variant();
+  const bool vec = (a.W % 4 == 0) && !(variant & 2) && (reinterpret_cast<uintptr_t>(a.src1) % 16 == 0) &&
+                   (a.src2 == nullptr || reinterpret_cast<uintptr_t>(a.src2) % 16 == 0);
+  const bool pref = !(variant & 1);
+  if constexpr (FC * FP == 8) {
+    const bool pipe = ((variant & 4) != 0) != (SGMSE_CONV_PIPE_DEFAULT != 0);
+    if (vec && pipe) { DRT_LAUNCH((conv_mfma_pipe_kernel<KS, WC, FC, FP>), grid, dim3(256), st, a); return; }
+  }
+  if (vec && pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 1>), grid, dim3(256), st, a);
+  else if (vec) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 1>), grid, dim3(256), st, a);
+  else if (pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 0>), grid, dim3(256), st, a);
+  else DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 0>), grid, dim3(256), st, a);
+}
+
+inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1) {
+#define SGMSE_CONV_CASE(KS_, CO_, ROWS_, WC_, FC_, FP_) \
+  if (ks == KS_ && pl.co_t == CO_ && pl.rows == ROWS_) { launch_conv_mfma_t<KS_, WC_, FC_, FP_>(a, st, variant); return; }
+  SGMSE_CONV_CASE(3, 128, 8, 2, 2, 4)
+  SGMSE_CONV_CASE(3, 64, 8, 2, 1, 4)
+  SGMSE_CONV_CASE(3, 32, 8, 1, 1, 2)
+  SGMSE_CONV_CASE(3, 128, 4, 2, 2, 2)
+  SGMSE_CONV_CASE(3, 64, 4, 2, 1, 2)
+  SGMSE_CONV_CASE(3, 32, 4, 1, 1, 1)
+  SGMSE_CONV_CASE(1, 128, 8, 2, 2, 4)
+  SGMSE_CONV_CASE(1, 64, 8, 2, 1, 4)
+  SGMSE_CONV_CASE(1, 32, 8, 1, 1, 2)
+  SGMSE_CONV_CASE(1, 128, 4, 2, 2, 2)
+  SGMSE_CONV_CASE(1, 64, 4, 2, 1, 2)
+  SGMSE_CONV_CASE(1, 32, 4, 1, 1, 1)
+#undef SGMSE_CONV_CASE
+}
+
+inline void launch_conv_direct(const ConvArgs& a, int ks, drt::stream_t st) {
+  const int HW = a.H * a.W;
+  if (a.Cout <= 4) {
+    dim3 grid((HW + 255) / 256, 1, a.B);
+    if (ks == 3) DRT_LAUNCH((conv_direct_kernel<3, 4>), grid, dim3(256), st, a);
+    else DRT_LAUNCH((conv_direct_kernel<1, 4>), grid, dim3(256), st, a);
+  } else {
+    dim3 grid((HW + 255) / 256, (a.Cout + 15) / 16, a.B);
+    if (ks == 3) DRT_LAUNCH((conv_direct_kernel<3, 16>), grid, dim3(256), st, a);
+    else DRT_LAUNCH((conv_direct_kernel<1, 16>), grid, dim3(256), st, a);
+  }
+}
+
+}  // namespace sgmse

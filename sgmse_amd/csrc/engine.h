@@ -15,6 +15,7 @@
 
 #include <sgmse_devrt.h>
 #include "kernels_conv.h"
+#include "conv_launch.h"
 #include "kernels_norm_fir.h"
 #include "kernels_attn_misc.h"
 #include "kernels_stft.h"

@@ -78,6 +78,73 @@ struct ConvTile {
   static constexpr int NW4 = (W_ELEMS / 4 + 255) / 256;
 };
 
+// Epilogue shared by the MFMA kernels: D[co = regs][px = lanes] -> NCHW rows, + bias, + time-embedding bias row,
+// + residual, * out_scale, and (optionally) the per-(b, co, sub-tile) GroupNorm partial sums of the stored values.
+template <class T, int FC, int FP, int WC>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[FC][FP], int b, int co_blk, int tx, int ty,
+                                              int tiles_x, int wc, int wp, int l31, int kh) {
+  constexpr int CO_T = T::CO_T, ROWS = T::ROWS;
+  const int H = p.H, W = p.W;
+  const int x0 = tx * 32, y0 = ty * ROWS;
+  const int x = x0 + l31;
+  const float* b2 = nullptr;
+  if (p.bias2) {
+    const int step = p.step_ptr ? *p.step_ptr : 0;
+    b2 = p.bias2 + (size_t)step * p.bias2_sstride + (size_t)b * p.bias2_bstride;
+  }
+#pragma unroll
+  for (int i = 0; i < FC; ++i) {
+    const int co_base = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh;
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co_base + (r & 3) + 8 * (r >> 2);
+      float t = 0.f;
+      if (co < p.Cout) {
+        if (p.bias) t += p.bias[co];
+        if (b2) t += b2[co];
+      }
+      bv[r] = t;
+    }
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < FP; ++j) {
+      const int y = y0 + wp * FP + j;
+      if (y < H && x < W) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_base + (r & 3) + 8 * (r >> 2);
+          if (co < p.Cout) {
+            const size_t o = ((size_t)(b * p.Cout + co) * H + y) * W + x;
+            float v = acc[i][j][r] + bv[r];
+            if (p.res) v += p.res[o];
+            v *= p.out_scale;
+            p.out[o] = v;
+            ssum[r] += v;
+            ssq[r] += v * v;
+          }
+        }
+      }
+    }
+    if (p.stats_out) {   // wave-uniform
+      const int sub = (ty * tiles_x + tx) * T::WP + wp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float a1 = ssum[r], a2 = ssq[r];
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) { a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
+        const int co = co_base + (r & 3) + 8 * (r >> 2);
+        if (l31 == 0 && co < p.Cout) {
+          float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + sub) * 2;
+          so[0] = a1; so[1] = a2;
+        }
+      }
+    }
+  }
+}
+
 // PREF = 1: the LDS operand reads of k-step s+1 are issued before the MFMAs of k-step s (order pinned with
 //           sched_group_barrier), so a wave does not park on lgkmcnt between MFMA groups.  PREF = 0: compiler order.
 // VEC  = 1: float4 input staging (needs W % 4 == 0 and 16-byte aligned sources); 0: element-wise staging.
@@ -322,64 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     __syncthreads();
   }
 
-  // epilogue: D[co = regs][px = lanes] -> NCHW rows
-  const int x = x0 + l31;
-  const float* b2 = nullptr;
-  if (p.bias2) {
-    const int step = p.step_ptr ? *p.step_ptr : 0;
-    b2 = p.bias2 + (size_t)step * p.bias2_sstride + (size_t)b * p.bias2_bstride;
-  }
-#pragma unroll
-  for (int i = 0; i < FC; ++i) {
-    const int co_base = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh;
-    float bv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co_base + (r & 3) + 8 * (r >> 2);
-      float t = 0.f;
-      if (co < p.Cout) {
-        if (p.bias) t += p.bias[co];
-        if (b2) t += b2[co];
-      }
-      bv[r] = t;
-    }
-    float ssum[16], ssq[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < FP; ++j) {
-      const int y = y0 + wp * FP + j;
-      if (y < H && x < W) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co_base + (r & 3) + 8 * (r >> 2);
-          if (co < p.Cout) {
-            const size_t o = ((size_t)(b * p.Cout + co) * H + y) * W + x;
-            float v = acc[i][j][r] + bv[r];
-            if (p.res) v += p.res[o];
-            v *= p.out_scale;
-            p.out[o] = v;
-            ssum[r] += v;
-            ssq[r] += v * v;
-          }
-        }
-      }
-    }
-    if (p.stats_out) {   // wave-uniform
-      const int sub = (ty * tiles_x + tx) * T::WP + wp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float a1 = ssum[r], a2 = ssq[r];
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) { a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
-        const int co = co_base + (r & 3) + 8 * (r >> 2);
-        if (l31 == 0 && co < p.Cout) {
-          float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + sub) * 2;
-          so[0] = a1; so[1] = a2;
-        }
-      }
-    }
-  }
+  conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
 }
 
 // Direct (VALU) convolution: one thread per output pixel, CG output channels per thread.
@@ -471,59 +481,6 @@ inline ConvPlan choose_conv_plan(int ks, int cin, int cout, int H, int W) {
 inline size_t packed_weight_elems(int ks, int cin, int cout, int co_t) {
   const int nblk = (cout + co_t - 1) / co_t;
   return (size_t)nblk * cin * ks * ks * co_t;
-}
-
-// Measurement knob SGMSE_CONV_VARIANT (also the `variant` argument of sgmse_bench_conv):
-//   bit 0: operand prefetch off (compiler-ordered LDS reads)   bit 1: element-wise instead of float4 input staging
-inline int conv_variant() {
-  static int v = [] { const char* e = getenv("SGMSE_CONV_VARIANT"); return e ? atoi(e) : 0; }();
-  return v;
-}
-
-template <int KS, int WC, int FC, int FP>
-inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant) {
-  using T = ConvTile<KS, WC, FC, FP>;
-  const int tiles = a.B * ((a.H + T::ROWS - 1) / T::ROWS) * ((a.W + 31) / 32);
-  dim3 grid(tiles, (a.Cout + T::CO_T - 1) / T::CO_T, 1);
-  if (variant < 0) variant = conv_variant();
-  const bool vec = (a.W % 4 == 0) && !(variant & 2) && (reinterpret_cast<uintptr_t>(a.src1) % 16 == 0) &&
-                   (a.src2 == nullptr || reinterpret_cast<uintptr_t>(a.src2) % 16 == 0);
-  const bool pref = !(variant & 1);
-  if (vec && pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 1>), grid, dim3(256), st, a);
-  else if (vec) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 1>), grid, dim3(256), st, a);
-  else if (pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 0>), grid, dim3(256), st, a);
-  else DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 0>), grid, dim3(256), st, a);
-}
-
-inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1) {
-#define SGMSE_CONV_CASE(KS_, CO_, ROWS_, WC_, FC_, FP_) \
-  if (ks == KS_ && pl.co_t == CO_ && pl.rows == ROWS_) { launch_conv_mfma_t<KS_, WC_, FC_, FP_>(a, st, variant); return; }
-  SGMSE_CONV_CASE(3, 128, 8, 2, 2, 4)
-  SGMSE_CONV_CASE(3, 64, 8, 2, 1, 4)
-  SGMSE_CONV_CASE(3, 32, 8, 1, 1, 2)
-  SGMSE_CONV_CASE(3, 128, 4, 2, 2, 2)
-  SGMSE_CONV_CASE(3, 64, 4, 2, 1, 2)
-  SGMSE_CONV_CASE(3, 32, 4, 1, 1, 1)
-  SGMSE_CONV_CASE(1, 128, 8, 2, 2, 4)
-  SGMSE_CONV_CASE(1, 64, 8, 2, 1, 4)
-  SGMSE_CONV_CASE(1, 32, 8, 1, 1, 2)
-  SGMSE_CONV_CASE(1, 128, 4, 2, 2, 2)
-  SGMSE_CONV_CASE(1, 64, 4, 2, 1, 2)
-  SGMSE_CONV_CASE(1, 32, 4, 1, 1, 1)
-#undef SGMSE_CONV_CASE
-}
-
-inline void launch_conv_direct(const ConvArgs& a, int ks, drt::stream_t st) {
-  const int HW = a.H * a.W;
-  if (a.Cout <= 4) {
-    dim3 grid((HW + 255) / 256, 1, a.B);
-    if (ks == 3) DRT_LAUNCH((conv_direct_kernel<3, 4>), grid, dim3(256), st, a);
-    else DRT_LAUNCH((conv_direct_kernel<1, 4>), grid, dim3(256), st, a);
-  } else {
-    dim3 grid((HW + 255) / 256, (a.Cout + 15) / 16, a.B);
-    if (ks == 3) DRT_LAUNCH((conv_direct_kernel<3, 16>), grid, dim3(256), st, a);
-    else DRT_LAUNCH((conv_direct_kernel<1, 16>), grid, dim3(256), st, a);
-  }
 }
 
 }  // namespace sgmse

@@ -24,6 +24,18 @@ def test_conv_direct(emu, shape):
     P.check_conv(emu, *shape, direct=True)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6])
+def test_conv_kernel_variants(emu, variant):
+    """Every selectable structure of the MFMA convolution (operand prefetch on/off, float4 / element-wise staging, the
+    software-pipelined kernel) computes the same convolution."""
+    import subprocess, sys
+    from conftest import EMU_LIB, ROOT
+    env = dict(os.environ, SGMSE_CONV_VARIANT=str(variant), PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py"), EMU_LIB, "cpu"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert "VARIANT-OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_conv_thin_output_on_padded_mfma_tile(emu):
     P.check_conv(emu, 1, 64, 4, 9, 33, 3, xform=True)
     P.check_conv(emu, 2, 128, 4, 4, 8, 3, xform=True)

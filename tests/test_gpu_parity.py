@@ -24,6 +24,16 @@ def test_conv_mfma(hip, shape):
     P.check_conv(hip, *shape)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+def test_conv_kernel_variants(hip, variant):
+    import os, subprocess, sys
+    from conftest import HIP_LIB, ROOT
+    env = dict(os.environ, SGMSE_CONV_VARIANT=str(variant), PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py"), HIP_LIB, "cuda"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert "VARIANT-OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_conv_mfma_fused_groupnorm_statistics_path(hip):
     """Network-level check of the epilogue-fused GroupNorm statistics against the stand-alone statistics pass: the two
     engines must agree to rounding (same network, SGMSE_FUSE_GN_STATS toggled in a child process)."""

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import torch
 from sgmse_amd import _lib
 
-VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,1,2").split(",")]
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,4").split(",")]
 ALL_SHAPES = [  # ks, B, Cin, Cout, H, W
     (3, 8, 128, 128, 256, 512),
     (3, 8, 256, 128, 256, 512),
