@@ -4,7 +4,7 @@
 #include "kernels_conv_pipe.h"
 
 #ifndef SGMSE_CONV_PIPE_DEFAULT
-#define SGMSE_CONV_PIPE_DEFAULT 0
+#define SGMSE_CONV_PIPE_DEFAULT 1
 #endif
 
 namespace sgmse {

@@ -494,6 +494,8 @@ class Engine {
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
     SG_REQUIRE(pl.mfma, "bench_conv: shape is not MFMA-eligible");
     if (variant >= 0 && (variant & 512)) { pl.rows = 4; variant &= ~512; }   // measurement knob: 128 co x 128 px tile
+    int ablate = 0;
+    if (variant >= 0) { ablate = (variant >> 12) & 15; variant &= 4095; }       // measurement knob: ablation bits 12..15
     const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * Cout * H * W, nw = (size_t)Cout * Cin * ks * ks;
     const size_t ne = packed_weight_elems(ks, Cin, Cout, pl.co_t);
     float* x = static_cast<float*>(dev_alloc_tmp(nx * 4));
@@ -511,6 +513,7 @@ class Engine {
     DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, pa);
     ConvArgs a{};
     a.src1 = x; a.C1 = Cin; a.w = pk; a.out = o; a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.out_scale = 1.f;
+    a.ablate = ablate;
     if (fused) { a.in_scale = sc; a.in_shift = sc + (size_t)B * Cin; a.in_act = 1; a.res = r; a.bias = w; a.out_scale = 0.70710678f; }
     drt::event_t e0{}, e1{};
     drt::event_create(&e0); drt::event_create(&e1);

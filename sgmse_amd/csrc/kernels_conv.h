@@ -47,6 +47,9 @@ struct ConvArgs {
   // {sum, sum of squares}; sub-tile = (tile index in the image) * WP + (pixel-wave index).  Deterministic (no atomics).
   float* stats_out;
   int stats_nsub;
+  // measurement-only ablation switches for sgmse_bench_conv (results are then WRONG on purpose): bit 0 skip the
+  // epilogue's global stores, bit 1 skip the residual read, bit 2 stage only the first K-stage, bit 3 skip the barriers
+  int ablate;
 };
 
 // SiLU x*sigmoid(x) (nn.SiLU, reference layers.py:38-39) on the hardware exp2/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each,
@@ -109,8 +112,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
     float ssum[16], ssq[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+    // residual: the 16 values of fragment row j+1 are loaded (independent, unconditional, clamped addresses) before the
+    // adds and stores of row j -- issued one by one behind their dependent add + store, the residual read cost 11 % of the
+    // kernel (profiles/r01_conv_ablation.txt); a whole-column batch (FP*16 registers) spills
+    const bool has_res = p.res && !(p.ablate & 2);
+    float rr[2][16];
+    auto load_res = [&](int j, int slot) {
+      const int y = y0 + wp * FP + j;
+      const bool pok = y < H && x < W;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_base + (r & 3) + 8 * (r >> 2);
+        const bool ok = pok && co < p.Cout;
+        const size_t o = ok ? ((size_t)(b * p.Cout + co) * H + y) * W + x : 0;
+        const float t = p.res[o];
+        rr[slot][r] = ok ? t : 0.f;
+      }
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { rr[0][r] = 0.f; rr[1][r] = 0.f; }
+    if (has_res) load_res(0, 0);          // wave-uniform branch: layers without a residual pay nothing
 #pragma unroll
     for (int j = 0; j < FP; ++j) {
+      if (has_res && j + 1 < FP) load_res(j + 1, (j + 1) & 1);
       const int y = y0 + wp * FP + j;
       if (y < H && x < W) {
 #pragma unroll
@@ -118,10 +142,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
           const int co = co_base + (r & 3) + 8 * (r >> 2);
           if (co < p.Cout) {
             const size_t o = ((size_t)(b * p.Cout + co) * H + y) * W + x;
-            float v = acc[i][j][r] + bv[r];
-            if (p.res) v += p.res[o];
-            v *= p.out_scale;
-            p.out[o] = v;
+            float v = (acc[i][j][r] + bv[r] + rr[j & 1][r]) * p.out_scale;
+            if (!(p.ablate & 1)) p.out[o] = v;
+            else if (v == 12345.678f) p.out[o] = v;   // keeps the value live without storing
             ssum[r] += v;
             ssq[r] += v * v;
           }
@@ -381,12 +404,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
   const int nstages = Cin / KC;
   load_stage(0);
   __syncthreads();  // s_sc / s_sh visible
+  const bool abl_stage = p.ablate & 4, abl_bar = p.ablate & 8;
   for (int ci = 0; ci < nstages; ++ci) {
-    store_stage(ci * KC);
-    __syncthreads();
-    if (ci + 1 < nstages) load_stage((ci + 1) * KC);   // in flight during the MFMAs
+    if (!abl_stage || ci == 0) store_stage(ci * KC);
+    if (!abl_bar) __syncthreads();
+    if (ci + 1 < nstages && !abl_stage) load_stage((ci + 1) * KC);   // in flight during the MFMAs
     compute();
-    __syncthreads();
+    if (!abl_bar) __syncthreads();
   }
 
   conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
