@@ -226,7 +226,7 @@ def main():
             traffic, traffic_note = hbm_traffic_of_dominant_kernel()
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-                               "kernel": "conv_mfma_kernel<3,2,2,4,*> (3x3 fp32 implicit GEMM, 128co x 256px tile)",
+                               "kernel": "conv_mfma_pipe_kernel<3,2,2,4> (3x3 fp32 MFMA implicit GEMM, 128 co x 256 px tile)",
                                "launches_per_eval": dom["launches"],
                                "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),
                                "flop_per_launch_avg": dom["work"] / max(dom["launches"], 1)}
