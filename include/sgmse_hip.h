@@ -33,7 +33,8 @@ typedef enum { SGMSE_OK = 0, SGMSE_EINVAL = -1, SGMSE_ERUNTIME = -2, SGMSE_ENOTR
  * combine_method='sum', embedding_type='fourier', conditional=True, centered=True, nonlinearity='swish',
  * init_scale=0, dropout=0. */
 typedef struct {
-  int variant;            /* 0: "ncsnpp" (ncsnpp.py), 1: "ncsnpp_48k" (ncsnpp_48k.py: output_layer before /t) */
+  int variant;            /* 0: "ncsnpp" (ncsnpp.py) and, with scale_by_sigma = 0, "ncsnpp_v2" (ncsnpp_v2.py: same network, no /t);
+                             1: "ncsnpp_48k" (ncsnpp_48k.py: output_layer before /t) */
   int nf;                 /* base width (128) */
   int n_levels;           /* len(ch_mult) (7) */
   int ch_mult[8];         /* (1,1,2,2,2,2,2) */
@@ -60,6 +61,11 @@ typedef struct {
   float theta;            /* OUVESDE.theta */
   float std1;             /* OUVESDE._std(T=1) for prior_sampling (sdes.py:224-229) */
   const float* t; const float* dt; const float* ald_eps; const float* ald_noise; const float* G; const float* G2;
+  /* ScoreModel.forward as an affine wrapper of the backbone output F (model.py:284-310): the network sees in_scale*x_t and
+   * in_scale*y, score = score_alpha*x_t + score_beta*F.  Host arrays [N], all three or all NULL.  NULL = old-code branch
+   * (model.py:307-310): in_scale 1, alpha 0, beta -1.  ncsnpp_v2 models: in_scale = c_in(t); 'score_matching': alpha =
+   * c_skip(t), beta = c_out(t)*s(t); 'denoiser': alpha = -1/std(t)^2, beta = s(t)/std(t)^2; s = network_scaling. */
+  const float* in_scale; const float* score_alpha; const float* score_beta;
   int use_graph;          /* 1: capture one predictor-corrector step as a hipGraph and replay it N times */
 } sgmse_sampler_cfg;
 

@@ -70,6 +70,7 @@ def main():
         "fwd_nf32": (NO.NetCfg.for_variant("ncsnpp", nf=32), 2, 256, 64),
         "fwd_nf128": (NO.NetCfg.for_variant("ncsnpp"), 1, 256, 64),
         "fwd_48k_nf32": (NO.NetCfg.for_variant("ncsnpp_48k", nf=32), 1, 192, 64),
+        "fwd_v2_nf32": (NO.NetCfg.for_variant("ncsnpp_v2", nf=32), 1, 256, 64),
     }
     for name, (cfg, B, Fq, T) in cases.items():
         P = synth.synth_params(cfg, seed=0)
@@ -78,7 +79,7 @@ def main():
         x = torch.randn(B, 2, Fq, T, dtype=torch.complex64, generator=g) * 0.3
         t = torch.rand(B, generator=g) * 0.9 + 0.05
         with torch.no_grad():
-            o_ref = m(x, t)
+            o_ref = m(x[:, :1], x[:, 1:], t) if cfg.variant == "ncsnpp_v2" else m(x, t)   # ncsnpp_v2.forward(x, y, t)
             o_orc = NO.ncsnpp_forward(P, cfg, x, t)
         r = rel(o_orc, o_ref)
         report.append((name, r))

@@ -40,6 +40,8 @@ class NetCfg:
     def for_variant(variant: str, **kw) -> "NetCfg":
         if variant == "ncsnpp":
             return NetCfg(variant="ncsnpp", **kw)
+        if variant == "ncsnpp_v2":       # ncsnpp_v2.py:50-66: the ncsnpp graph; forward(x, y, t) without the final /t
+            return NetCfg(variant="ncsnpp_v2", **kw)
         if variant == "ncsnpp_48k":      # ncsnpp_48k.py:59,66-67
             base = dict(attn_resolutions=(), progressive="none", progressive_input="none")
             base.update(kw)
@@ -337,6 +339,8 @@ def ncsnpp_forward(P: Dict[str, torch.Tensor], cfg: NetCfg, x: torch.Tensor, t: 
         h = F.conv2d(h, ow, ob)
         if cfg.scale_by_sigma:
             h = h / t[:, None, None, None]
+    elif cfg.variant == "ncsnpp_v2":                                   # ncsnpp_v2.py:388-394: no division by t
+        h = F.conv2d(h, ow, ob)
     else:                                                              # ncsnpp.py:411-416
         if cfg.scale_by_sigma:
             h = h / t[:, None, None, None]
@@ -348,3 +352,33 @@ def ncsnpp_forward(P: Dict[str, torch.Tensor], cfg: NetCfg, x: torch.Tensor, t: 
 def score_fn(P, cfg, x_t, y, t):
     """ScoreModel.forward, old-code branch (model.py:307-310)."""
     return -ncsnpp_forward(P, cfg, torch.cat([x_t, y], dim=1), t)
+
+
+def score_fn_v2(P, cfg, sde, x_t, y, t, loss_type="score_matching", network_scaling=None, c_in="1", c_out="1", c_skip="0",
+                sigma_data=0.1):
+    """ScoreModel.forward, new-code branch for backbone 'ncsnpp_v2' (model.py:284-304 with _c_in/_c_out/_c_skip :312-341).
+    ``sde`` provides std(t) (OUVESDE._std)."""
+    b4 = lambda v: v[:, None, None, None]
+    std = sde.std(t)
+    cin = 1.0 if c_in == "1" else b4(1.0 / torch.sqrt(std ** 2 + sigma_data ** 2))
+    if c_out == "1":
+        cout = 1.0
+    elif c_out == "sigma":
+        cout = b4(std)
+    elif c_out == "1/sigma":
+        cout = 1.0 / b4(std)
+    else:                                                              # "edm"
+        cout = b4((std * sigma_data) / torch.sqrt(sigma_data ** 2 + std ** 2))
+    cskip = 0.0 if c_skip == "0" else b4(sigma_data ** 2 / (std ** 2 + sigma_data ** 2))
+    Fo = ncsnpp_forward(P, cfg, torch.cat([cin * x_t, cin * y], dim=1), t)
+    if network_scaling == "1/sigma":
+        Fo = Fo / b4(std)
+    elif network_scaling == "1/t":
+        Fo = Fo / b4(t)
+    if loss_type == "score_matching":
+        return cskip * x_t + cout * Fo
+    if loss_type == "denoiser":
+        return (Fo - x_t) / b4(std).pow(2)
+    if loss_type == "data_prediction":
+        return cskip * x_t + cout * Fo
+    raise ValueError(loss_type)

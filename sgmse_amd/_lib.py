@@ -35,6 +35,7 @@ class SamplerCfgC(C.Structure):
                 ("probability_flow", C.c_int), ("denoise", C.c_int), ("theta", C.c_float), ("std1", C.c_float),
                 ("t", C.POINTER(C.c_float)), ("dt", C.POINTER(C.c_float)), ("ald_eps", C.POINTER(C.c_float)),
                 ("ald_noise", C.POINTER(C.c_float)), ("G", C.POINTER(C.c_float)), ("G2", C.POINTER(C.c_float)),
+                ("in_scale", C.POINTER(C.c_float)), ("score_alpha", C.POINTER(C.c_float)), ("score_beta", C.POINTER(C.c_float)),
                 ("use_graph", C.c_int)]
 
 
@@ -242,7 +243,9 @@ class Context:
 
     def pc_sample(self, Y: torch.Tensor, table: Dict[str, torch.Tensor], *, theta: float, std1: float,
                   corrector: str, corrector_steps: int, predictor: str, probability_flow: bool, denoise: bool,
-                  noise: Optional[torch.Tensor], seed: int, use_graph: bool = True):
+                  noise: Optional[torch.Tensor], seed: int, use_graph: bool = True, affine=None):
+        """``affine``: optional (in_scale, score_alpha, score_beta) fp32 tensors of length N: the score wrapper of
+        ScoreModel.forward's new-code branch (ncsnpp_v2); None = old-code branch (score = -F)."""
         Y = check_tensor(Y, "y", torch.complex64, self.device)
         if Y.dim() != 4 or Y.shape[1] != 1:
             raise ValueError(f"expected y of shape [B,1,F,T], got {tuple(Y.shape)}")
@@ -260,6 +263,11 @@ class Context:
             v = table[k].detach().to("cpu", torch.float32).contiguous()
             keep[k] = v
             setattr(cfg, k, C.cast(v.data_ptr(), C.POINTER(C.c_float)))
+        if affine is not None:
+            for k, v in zip(("in_scale", "score_alpha", "score_beta"), affine):
+                v = torch.as_tensor(v, dtype=torch.float32).detach().to("cpu").expand(N).contiguous()
+                keep[k] = v
+                setattr(cfg, k, C.cast(v.data_ptr(), C.POINTER(C.c_float)))
         if noise is not None:
             noise = check_tensor(noise, "noise", torch.complex64, self.device)
             ncorr = cfg.corrector_steps if cfg.corrector else 0

@@ -1,4 +1,4 @@
 from .shared import BackboneRegistry
-from .ncsnpp import NCSNpp, NCSNpp_48k
+from .ncsnpp import NCSNpp, NCSNpp_48k, NCSNpp_v2
 
-__all__ = ["BackboneRegistry", "NCSNpp", "NCSNpp_48k"]
+__all__ = ["BackboneRegistry", "NCSNpp", "NCSNpp_48k", "NCSNpp_v2"]

@@ -202,3 +202,29 @@ class NCSNpp_48k(NCSNpp):
 
     VARIANT = "ncsnpp_48k"
     DEFAULTS = dict(attn_resolutions=(), progressive="none", progressive_input="none")
+
+
+@BackboneRegistry.register("ncsnpp_v2")
+class NCSNpp_v2(NCSNpp):
+    """Backbone of the ICASSP-2025 / Schroedinger-bridge checkpoints (reference ncsnpp_v2.py:36-395): the ncsnpp graph with
+    ``forward(x, y, t)`` (x_t and y passed separately, ncsnpp_v2.py:241-247) and no division by t at the output
+    (ncsnpp_v2.py:388-394).  All output scaling lives in ScoreModel.forward (model.py:284-304)."""
+
+    VARIANT = "ncsnpp"
+
+    @staticmethod
+    def add_argparse_args(parser):
+        parser.add_argument("--nf", type=int, default=128)
+        parser.add_argument("--ch_mult", type=int, nargs="+", default=[1, 1, 2, 2, 2, 2, 2])
+        parser.add_argument("--num_res_blocks", type=int, default=2)
+        parser.add_argument("--attn_resolutions", type=int, nargs="+", default=[16])
+        return parser
+
+    def __init__(self, **kwargs):
+        kwargs.pop("scale_by_sigma", None)
+        kwargs.pop("conditional", None)
+        kwargs.pop("centered", None)
+        super().__init__(scale_by_sigma=False, **kwargs)
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        return super().forward(torch.cat([x, y], dim=1), t)

@@ -103,6 +103,7 @@ int sgmse_pc_sample(sgmse_ctx* ctx, const void* Y, void* out, int B, int F, int 
     s.N = cfg->N; s.corrector = cfg->corrector; s.corrector_steps = cfg->corrector_steps; s.predictor = cfg->predictor;
     s.probability_flow = cfg->probability_flow; s.denoise = cfg->denoise; s.theta = cfg->theta; s.std1 = cfg->std1;
     s.t = cfg->t; s.dt = cfg->dt; s.ald_eps = cfg->ald_eps; s.ald_noise = cfg->ald_noise; s.G = cfg->G; s.G2 = cfg->G2;
+    s.in_scale = cfg->in_scale; s.score_alpha = cfg->score_alpha; s.score_beta = cfg->score_beta;
     s.use_graph = cfg->use_graph;
     e.pc_sample((const float2*)Y, (float2*)out, B, F, T, s, (const float2*)noise, seed);
     if (nfe) *nfe = e.last_nfe();

@@ -250,6 +250,8 @@ struct SamplerCfg {
   float std1 = 0.f;         // OUVE._std(T)
   const float* t = nullptr; const float* dt = nullptr; const float* ald_eps = nullptr; const float* ald_noise = nullptr;
   const float* G = nullptr; const float* G2 = nullptr;   // host arrays [N]
+  // score wrapper per step (host arrays [N], all three or none): network input scale, score = alpha*x_t + beta*F
+  const float* in_scale = nullptr; const float* score_alpha = nullptr; const float* score_beta = nullptr;
   int use_graph = 1;
 };
 
@@ -305,6 +307,7 @@ class Engine {
   struct FwdCtl {
     const float* bias_table; int bias_bstride, bias_sstride; const int* step_ptr;
     const float* tvals; int t_bstride, t_sstride; float sign;
+    const float* coef = nullptr; int coef_bstride = 0, coef_sstride = 0;   // score-wrapper rows {gamma, alpha, beta, -} or null
   };
 
   void forward_xy(const float2* xy, const float* t_dev, float2* out, int B, int F, int T) {
@@ -334,6 +337,13 @@ class Engine {
       if (sc.corrector) { r[SC_ALD_EPS] = sc.ald_eps[i]; r[SC_ALD_NOISE] = sc.ald_noise[i]; }
       tv[i] = sc.t[i];
     }
+    const bool affine = sc.in_scale && sc.score_alpha && sc.score_beta;
+    SG_REQUIRE(affine || (!sc.in_scale && !sc.score_alpha && !sc.score_beta), "pc_sample: give all three score-wrapper arrays or none");
+    if (affine) {
+      std::vector<float> cf((size_t)sc.N * 4, 0.f);
+      for (int i = 0; i < sc.N; ++i) { cf[4 * i] = sc.in_scale[i]; cf[4 * i + 1] = sc.score_alpha[i]; cf[4 * i + 2] = sc.score_beta[i]; }
+      SG_CHECK(drt::memcpy_h2d(coef_table_, cf.data(), cf.size() * 4, stream_));
+    }
     SG_CHECK(drt::memcpy_h2d(step_table_, tab.data(), tab.size() * 4, stream_));
     SG_CHECK(drt::memcpy_h2d(tsteps_, tv.data(), tv.size() * 4, stream_));
     SG_CHECK(drt::stream_sync(stream_));
@@ -357,6 +367,7 @@ class Engine {
     DRT_LAUNCH(step_set_kernel, dim3(1), dim3(64), stream_, step_ctr_, 0);
 
     FwdCtl ctl{bias_table_, 0, tot_temb_, step_ctr_, tsteps_, 0, 1, -1.0f};
+    if (affine) { ctl.coef = coef_table_; ctl.coef_bstride = 0; ctl.coef_sstride = 1; }
     const long long FT = (long long)F * T;
     auto step_body = [&]() {
       for (int cs = 0; cs < ncorr; ++cs) {
@@ -374,7 +385,7 @@ class Engine {
       DRT_LAUNCH(step_inc_kernel, dim3(1), dim3(64), stream_, step_ctr_);
     };
 
-    GraphKey key{B, F, T, sc.corrector, ncorr, sc.predictor, sc.probability_flow, (const void*)Y, (const void*)noise, seed,
+    GraphKey key{B, F, T, sc.corrector, ncorr, sc.predictor, sc.probability_flow + (affine ? 2 : 0), (const void*)Y, (const void*)noise, seed,
                  sc.theta, draws_per_step};
     const bool want_graph = sc.use_graph && drt::graphs_supported();
     if (want_graph) {
@@ -702,12 +713,13 @@ class Engine {
     }
     if (nrows > temb_rows_) {
       invalidate_graph();
-      if (temb_act_) { dev_free_owned(temb_act_); dev_free_owned(bias_table_); dev_free_owned(step_table_); dev_free_owned(tsteps_); }
+      if (temb_act_) { dev_free_owned(temb_act_); dev_free_owned(bias_table_); dev_free_owned(step_table_); dev_free_owned(tsteps_); dev_free_owned(coef_table_); }
       temb_rows_ = std::max(nrows, 64);
       temb_act_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * 4 * cfg_.nf * 4));
       bias_table_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * std::max(tot_temb_, 1) * 4));
       step_table_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * SC_STRIDE * 4));
       tsteps_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * 4));
+      coef_table_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * 16));
     }
   }
 
@@ -893,7 +905,8 @@ class Engine {
     const int FT = F * T;
 
     Tensor xr = new_tensor(4, F, T);
-    if (!dry_) { tock(); DRT_LAUNCH(entry_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, x, xbs, y, ybs, xr.p, FT); tick(TC_MISC, 32.0 * B * FT); }
+    if (!dry_) { tock(); const WrapCoef wc{ctl.coef, ctl.coef_bstride, ctl.coef_sstride, ctl.step_ptr, ctl.sign};
+      DRT_LAUNCH(entry_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, x, xbs, y, ybs, xr.p, FT, wc); tick(TC_MISC, 32.0 * B * FT); }
     std::vector<Tensor> hs;
     {
       const Mod& m = next();
@@ -986,7 +999,8 @@ class Engine {
     SG_REQUIRE(mi == layout_.size(), "forward did not consume every module");
     if (!dry_) {
       ExitArgs ea{h4.p, Wp("output_layer.weight"), Wp("output_layer.bias"), ctl.tvals, ctl.t_bstride, ctl.t_sstride, ctl.step_ptr,
-                  c.variant == 1 ? 1 : 0, c.scale_by_sigma, ctl.sign, out, FT};
+                  c.variant == 1 ? 1 : 0, c.scale_by_sigma,
+                  WrapCoef{ctl.coef, ctl.coef_bstride, ctl.coef_sstride, ctl.step_ptr, ctl.sign}, x, xbs, out, FT};
       tock();
       DRT_LAUNCH(exit_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, ea);
       tick(TC_MISC, 24.0 * B * FT);
@@ -1024,7 +1038,7 @@ class Engine {
   int B_ = 0, shape_B_ = 0, shape_F_ = 0, shape_T_ = 0;
   float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr, *sy_ = nullptr; size_t samp_n_ = 0;
   int* step_ctr_ = nullptr;
-  float *temb_act_ = nullptr, *bias_table_ = nullptr, *step_table_ = nullptr, *tsteps_ = nullptr; int temb_rows_ = 0;
+  float *temb_act_ = nullptr, *bias_table_ = nullptr, *step_table_ = nullptr, *tsteps_ = nullptr, *coef_table_ = nullptr; int temb_rows_ = 0;
   drt::graph_t graph_{}; bool graph_valid_ = false; GraphKey graph_key_{};
   int nfe_ = 0;
   bool prof_ = false, ev_init_ = false; drt::event_t ev_a_{}, ev_b_{}; float prof_ms_[TC_COUNT]; double prof_flops_[TC_COUNT]; int prof_n_[TC_COUNT];

@@ -194,24 +194,41 @@ __global__ __launch_bounds__(256) void temb_dense_kernel(const DenseDesc* descs,
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Network entry (ncsnpp.py:262-263): complex x_t, y -> real [B][4][F*T] = (x.re, x.im, y.re, y.im).
+// Score-wrapper coefficients (reference ScoreModel.forward, model.py:284-310): the network sees gamma*x_t, gamma*y and the
+// score is  alpha * x_t + beta * F  with F the backbone output.  Old-code branch (ncsnpp / ncsnpp_48k, model.py:307-310):
+// gamma = 1, alpha = 0, beta = -1.  New-code branch (ncsnpp_v2): gamma = c_in(t); score_matching: alpha = c_skip(t),
+// beta = c_out(t) * s(t); denoiser: alpha = -1/sigma^2, beta = s(t)/sigma^2; s(t) = network_scaling (1, 1/sigma, 1/t).
+// coef rows of 4 floats {gamma, alpha, beta, -}; row = step * sstride + b * bstride; coef == null -> {1, 0, sign}.
+struct WrapCoef { const float* coef; int bstride, sstride; const int* step_ptr; float sign; };
+
+__device__ __forceinline__ void wrap_coef(const WrapCoef& w, int b, float* gamma, float* alpha, float* beta) {
+  if (!w.coef) { *gamma = 1.f; *alpha = 0.f; *beta = w.sign; return; }
+  const int step = w.step_ptr ? *w.step_ptr : 0;
+  const float* r = w.coef + ((size_t)step * w.sstride + (size_t)b * w.bstride) * 4;
+  *gamma = r[0]; *alpha = r[1]; *beta = r[2];
+}
+
+// Network entry (ncsnpp.py:262-263 / ncsnpp_v2.py:247): complex x_t, y -> real [B][4][F*T] = gamma*(x.re, x.im, y.re, y.im).
 __global__ __launch_bounds__(256) void entry_kernel(const float2* x, long long xbs, const float2* y, long long ybs,
-                                                    float* xr, int FT) {
+                                                    float* xr, int FT, WrapCoef w) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= FT) return;
   const int b = blockIdx.y;
+  float g, al, be;
+  wrap_coef(w, b, &g, &al, &be);
   const float2 xv = x[(size_t)b * xbs + i], yv = y[(size_t)b * ybs + i];
   float* o = xr + (size_t)b * 4 * FT + i;
-  o[0] = xv.x; o[FT] = xv.y; o[2 * (size_t)FT] = yv.x; o[3 * (size_t)FT] = yv.y;
+  o[0] = g * xv.x; o[FT] = g * xv.y; o[2 * (size_t)FT] = g * yv.x; o[3 * (size_t)FT] = g * yv.y;
 }
 
-// Network exit (ncsnpp.py:402-419 / ncsnpp_48k.py:414-421) fused with ScoreModel.forward's sign (model.py:309):
-//   ncsnpp    : h = h4 / t ; o = conv1x1(4->2)(h)        ncsnpp_48k: o = conv1x1(h4) ; o = o / t
-//   out = sign * complex(o0, o1)
+// Network exit (ncsnpp.py:402-419 / ncsnpp_48k.py:414-421 / ncsnpp_v2.py:388-394) fused with the score wrapper:
+//   ncsnpp    : h = h4 / t ; F = conv1x1(4->2)(h)        ncsnpp_48k: F = conv1x1(h4) ; F = F / t      ncsnpp_v2: F = conv1x1(h4)
+//   out = alpha * x_t + beta * complex(F0, F1)
 struct ExitArgs {
   const float* h4; const float* ow; const float* ob;
   const float* tvals; int t_bstride, t_sstride; const int* step_ptr;
-  int conv_first, scale_by_t; float sign;
+  int conv_first, scale_by_t;
+  WrapCoef w; const float2* xt; long long xt_bs;
   float2* out; int FT;
 };
 
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(256) void exit_kernel(ExitArgs p) {
   if (i >= p.FT) return;
   const int b = blockIdx.y;
   const int step = p.step_ptr ? *p.step_ptr : 0;
-  const float t = p.tvals[(size_t)step * p.t_sstride + (size_t)b * p.t_bstride];
+  const float t = p.scale_by_t ? p.tvals[(size_t)step * p.t_sstride + (size_t)b * p.t_bstride] : 1.f;
   const float* h = p.h4 + (size_t)b * 4 * p.FT + i;
   float hv[4];
 #pragma unroll
@@ -238,7 +255,11 @@ __global__ __launch_bounds__(256) void exit_kernel(ExitArgs p) {
     o[k] = acc + p.ob[k];
   }
   if (p.scale_by_t && p.conv_first) { o[0] = o[0] / t; o[1] = o[1] / t; }
-  p.out[(size_t)b * p.FT + i] = make_float2(p.sign * o[0], p.sign * o[1]);
+  float g, al, be;
+  wrap_coef(p.w, b, &g, &al, &be);
+  float2 r = make_float2(be * o[0], be * o[1]);
+  if (al != 0.f) { const float2 xv = p.xt[(size_t)b * p.xt_bs + i]; r.x += al * xv.x; r.y += al * xv.y; }
+  p.out[(size_t)b * p.FT + i] = r;
 }
 
 // ------------------------------------------------------------------------------------------------------

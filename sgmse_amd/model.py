@@ -24,7 +24,8 @@ from .util.other import pad_spec
 
 
 class ScoreModel(nn.Module):
-    _native_score_wrapper = True   # forward == -dnn(cat[x_t, y], t): the wrapper the fused HIP sampler implements
+    _native_score_wrapper = True   # forward is an affine wrapper of the backbone (score_affine): the fused HIP sampler applies
+                                   # it inside the network's entry / exit kernels
 
     @staticmethod
     def add_argparse_args(parser):
@@ -123,12 +124,80 @@ class ScoreModel(nn.Module):
 
     _step = training_step = validation_step = configure_optimizers = _loss
 
-    # -- score function (reference model.py:307-310, the branch every ncsnpp / ncsnpp_48k checkpoint takes) --------
+    # -- score function (reference model.py:264-341) ------------------------------------------------------------------------
+    def _c_in(self, t):
+        if self.c_in == "1":
+            return 1.0
+        if self.c_in == "edm":
+            sigma = self.sde._std(t)
+            return (1.0 / torch.sqrt(sigma ** 2 + self.sigma_data ** 2))[:, None, None, None]
+        raise ValueError("Invalid c_in type: {}".format(self.c_in))
+
+    def _c_out(self, t):
+        if self.c_out == "1":
+            return 1.0
+        if self.c_out == "sigma":
+            return self.sde._std(t)[:, None, None, None]
+        if self.c_out == "1/sigma":
+            return 1.0 / self.sde._std(t)[:, None, None, None]
+        if self.c_out == "edm":
+            sigma = self.sde._std(t)
+            return ((sigma * self.sigma_data) / torch.sqrt(self.sigma_data ** 2 + sigma ** 2))[:, None, None, None]
+        raise ValueError("Invalid c_out type: {}".format(self.c_out))
+
+    def _c_skip(self, t):
+        if self.c_skip == "0":
+            return 0.0
+        if self.c_skip == "edm":
+            sigma = self.sde._std(t)
+            return (self.sigma_data ** 2 / (sigma ** 2 + self.sigma_data ** 2))[:, None, None, None]
+        raise ValueError("Invalid c_skip type: {}".format(self.c_skip))
+
     def forward(self, x_t, y, t):
+        """Score of the perturbed spectrogram.  Old-code branch (ncsnpp / ncsnpp_48k, model.py:307-310):
+        -dnn(cat[x_t, y], t).  New-code branch (ncsnpp_v2, model.py:284-304): scaled inputs, network_scaling, and the
+        loss-type dependent output map.  The backbone runs on the HIP engine; the few element-wise operations of this
+        method are only used when the model is called directly (the fused sampler applies the same wrapper inside the
+        network's entry/exit kernels, see ``score_affine``)."""
         if self.backbone == "ncsnpp_v2":
-            raise NotImplementedError("ncsnpp_v2 (new-code branch, model.py:284-304) is a next-tier row, not built yet")
+            F = self.dnn(self._c_in(t) * x_t, self._c_in(t) * y, t)
+            if self.network_scaling == "1/sigma":
+                F = F / self.sde._std(t)[:, None, None, None]
+            elif self.network_scaling == "1/t":
+                F = F / t[:, None, None, None]
+            if self.loss_type == "score_matching":
+                return self._c_skip(t) * x_t + self._c_out(t) * F
+            if self.loss_type == "denoiser":
+                return (F - x_t) / self.sde._std(t)[:, None, None, None].pow(2)
+            if self.loss_type == "data_prediction":
+                return self._c_skip(t) * x_t + self._c_out(t) * F
+            raise ValueError("Invalid loss type: {}".format(self.loss_type))
         dnn_input = torch.cat([x_t, y], dim=1)
         return -self.dnn(dnn_input, t)
+
+    def score_affine(self, ts: torch.Tensor):
+        """The wrapper above as per-time-step scalars: the network sees in_scale*x_t, in_scale*y and
+        score = alpha*x_t + beta*F.  Returns None for the old-code branch (in_scale 1, alpha 0, beta -1, built into the
+        engine) or three fp32 tensors of len(ts) for ncsnpp_v2 models."""
+        if self.backbone != "ncsnpp_v2":
+            return None
+        ts = ts.to("cpu", torch.float32)
+        one = torch.ones_like(ts)
+        flat = lambda v: (v.reshape(-1) if torch.is_tensor(v) else one * v).to(torch.float32)
+        std = self.sde._std(ts)
+        scale = one
+        if self.network_scaling == "1/sigma":
+            scale = 1.0 / std
+        elif self.network_scaling == "1/t":
+            scale = 1.0 / ts
+        gamma = flat(self._c_in(ts))
+        if self.loss_type == "denoiser":
+            alpha, beta = -1.0 / std.pow(2), scale / std.pow(2)
+        elif self.loss_type in ("score_matching", "data_prediction"):
+            alpha, beta = flat(self._c_skip(ts)), flat(self._c_out(ts)) * scale
+        else:
+            raise ValueError("Invalid loss type: {}".format(self.loss_type))
+        return gamma, flat(alpha), flat(beta)
 
     # -- samplers (reference model.py:348-390) -----------------------------------------------------------------
     def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, **kwargs):

@@ -52,13 +52,15 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=Tru
     if ctx is not None:
         table = sde.step_table(eps, snr, sde.N)
         std1 = float(sde._std(torch.ones(1))[0])
+        affine = score_fn.score_affine(table["t"])
         # like the reference's Predictor (predictors.py:18) the PC sampler ignores probability_flow
         def native_pc_sampler():
             s = seed if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
             with torch.no_grad():
                 out, nfe = ctx.pc_sample(y, table, theta=float(sde.theta), std1=std1, corrector=corrector_name,
                                          corrector_steps=corrector_steps, predictor=predictor_name,
-                                         probability_flow=False, denoise=denoise, noise=noise, seed=s, use_graph=use_graph)
+                                         probability_flow=False, denoise=denoise, noise=noise, seed=s, use_graph=use_graph,
+                                         affine=affine)
             return out, nfe
         return native_pc_sampler
 
@@ -110,13 +112,14 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
 
     table = sde.step_table(eps, 0.0, sde.N)
     std1 = float(sde._std(torch.ones(1))[0])
+    affine = score_fn.score_affine(table["t"])
 
     def ode_sampler(z=None, **kw):
         s = seed if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
         with torch.no_grad():
             return ctx.pc_sample(y, table, theta=float(sde.theta), std1=std1, corrector="none", corrector_steps=1,
                                  predictor="reverse_diffusion", probability_flow=True, denoise=False, noise=noise, seed=s,
-                                 use_graph=use_graph)
+                                 use_graph=use_graph, affine=affine)
     return ode_sampler
 
 

@@ -98,6 +98,7 @@ NET_CASES = {
     "fwd_nf32": NO.NetCfg.for_variant("ncsnpp", nf=32),
     "fwd_48k_nf32": NO.NetCfg.for_variant("ncsnpp_48k", nf=32),
     "fwd_nf128": NO.NetCfg.for_variant("ncsnpp"),
+    "fwd_v2_nf32": NO.NetCfg.for_variant("ncsnpp_v2", nf=32),
 }
 
 
@@ -120,7 +121,10 @@ def check_forward_golden(dev, name, batch=None):
     ref = torch.from_numpy(z["out"])
     if batch is not None:
         x, t, ref = x[:batch], t[:batch], ref[:batch]
-    out = net(x.to(dev), t.to(dev))
+    if cfg.variant == "ncsnpp_v2":         # ncsnpp_v2.forward(x, y, t)
+        out = net(x[:, :1].contiguous().to(dev), x[:, 1:].contiguous().to(dev), t.to(dev))
+    else:
+        out = net(x.to(dev), t.to(dev))
     assert out.shape == ref.shape and out.dtype == torch.complex64
     assert rel_l2(out.cpu(), ref) < NET_TOL, name
 
@@ -222,4 +226,25 @@ def check_sampler_oracle(dev, variant="ncsnpp_48k", N=2, corrector="ald", snr=0.
     ref, nfe_ref = SO.pc_sample(so, lambda a, b, c: NO.score_fn(P, cfg, a, b, c), y, rep, eps=0.03, snr=snr, corrector=corrector)
     noise = torch.stack(rep.draws).to(dev)
     out, nfe = m.get_pc_sampler("reverse_diffusion", corrector, y.to(dev), N=N, snr=snr, noise=noise, use_graph=use_graph)()
+    assert nfe == nfe_ref and rel_l2(out.cpu(), ref) < SAMPLER_TOL
+
+
+def check_sampler_v2(dev, loss_type, network_scaling, c_in, c_out, c_skip, N=2, use_graph=True):
+    """ncsnpp_v2 model: the new-code ScoreModel.forward (model.py:284-304) -- scaled inputs, network scaling, loss-type
+    dependent output map -- applied inside the fused sampler, against the oracle loop over oracle.score_fn_v2; and the
+    directly called forward against the same oracle function."""
+    cfg = NO.NetCfg.for_variant("ncsnpp_v2", nf=32)
+    wrap = dict(loss_type=loss_type, network_scaling=network_scaling, c_in=c_in, c_out=c_out, c_skip=c_skip, sigma_data=0.1)
+    m, P = make_model(cfg, dev, **wrap)
+    y = synth.synth_spec(1, 256, 64, seed=4)
+    so = SO.OUVE(1.5, 0.05, 0.5, N)
+    score = lambda a, b, c: NO.score_fn_v2(P, cfg, so, a, b, c, **wrap)
+    g = torch.Generator().manual_seed(3)
+    xt = y + 0.3 * torch.randn(y.shape, dtype=torch.complex64, generator=g)
+    tt = torch.tensor([0.6])
+    assert rel_l2(m(xt.to(dev), y.to(dev), tt.to(dev)).cpu(), score(xt, y, tt)) < NET_TOL
+    rep = SO.NoiseReplay(7)
+    ref, nfe_ref = SO.pc_sample(so, score, y, rep, eps=0.03, snr=0.5)
+    noise = torch.stack(rep.draws).to(dev)
+    out, nfe = m.get_pc_sampler("reverse_diffusion", "ald", y.to(dev), N=N, snr=0.5, noise=noise, use_graph=use_graph)()
     assert nfe == nfe_ref and rel_l2(out.cpu(), ref) < SAMPLER_TOL

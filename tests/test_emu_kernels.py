@@ -77,6 +77,14 @@ def test_forward_matches_reference_ncsnpp(emu):
     P.check_forward_golden(emu, "fwd_nf32", batch=1)
 
 
+def test_forward_matches_reference_ncsnpp_v2(emu):
+    P.check_forward_golden(emu, "fwd_v2_nf32")
+
+
+def test_sampler_new_code_score_wrapper(emu):
+    P.check_sampler_v2(emu, "denoiser", "1/sigma", "edm", "1", "0", N=1)
+
+
 def test_forward_matches_reference_ncsnpp_48k(emu):
     P.check_forward_golden(emu, "fwd_48k_nf32")
 

@@ -88,7 +88,7 @@ def test_attention(hip, shape):
     P.check_attention(hip, *shape)
 
 
-@pytest.mark.parametrize("name", ["fwd_nf32", "fwd_48k_nf32", "fwd_nf128"])
+@pytest.mark.parametrize("name", ["fwd_nf32", "fwd_48k_nf32", "fwd_nf128", "fwd_v2_nf32"])
 def test_forward_matches_reference(hip, name):
     P.check_forward_golden(hip, name)
 
@@ -101,6 +101,12 @@ def test_samplers_match_reference(hip, tag):
 def test_sampler_48k_variant_against_oracle(hip):
     P.check_sampler_oracle(hip, "ncsnpp_48k", N=3, snr=0.33, F_=192, T=64, B=2)
     P.check_sampler_oracle(hip, "ncsnpp", N=2, corrector="none", snr=0.5, F_=256, T=128, B=1)
+
+
+@pytest.mark.parametrize("wrap", [("score_matching", None, "1", "1", "0"), ("score_matching", "1/t", "1", "sigma", "0"),
+                                  ("score_matching", None, "edm", "edm", "edm"), ("denoiser", "1/sigma", "edm", "1", "0")])
+def test_sampler_new_code_score_wrapper(hip, wrap):
+    P.check_sampler_v2(hip, *wrap, N=2)
 
 
 def test_sampler_graph_equals_eager(hip):

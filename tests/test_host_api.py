@@ -17,7 +17,7 @@ def test_registries_match_reference_names():
     from sgmse_amd.backbones import BackboneRegistry
     from sgmse_amd.sdes import SDERegistry
     from sgmse_amd.sampling import PredictorRegistry, CorrectorRegistry
-    assert set(BackboneRegistry.get_all_names()) >= {"ncsnpp", "ncsnpp_48k"}
+    assert set(BackboneRegistry.get_all_names()) >= {"ncsnpp", "ncsnpp_48k", "ncsnpp_v2"}
     assert "ouve" in SDERegistry.get_all_names()
     assert set(PredictorRegistry.get_all_names()) == {"euler_maruyama", "reverse_diffusion", "none"}
     assert set(CorrectorRegistry.get_all_names()) == {"langevin", "ald", "none"}

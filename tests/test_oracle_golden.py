@@ -21,6 +21,7 @@ def load(name):
     ("fwd_nf32", NO.NetCfg.for_variant("ncsnpp", nf=32)),
     ("fwd_48k_nf32", NO.NetCfg.for_variant("ncsnpp_48k", nf=32)),
     ("fwd_nf128", NO.NetCfg.for_variant("ncsnpp")),
+    ("fwd_v2_nf32", NO.NetCfg.for_variant("ncsnpp_v2", nf=32)),
 ])
 def test_network_forward_matches_reference(name, cfg):
     z = load(name)
