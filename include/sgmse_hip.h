@@ -53,7 +53,8 @@ typedef struct {
  * ald_eps = 2 (snr std(t))^2; ald_noise = sqrt(2 ald_eps); G = g(t) sqrt(dt); G2 = G^2. */
 typedef struct {
   int N;
-  int corrector;          /* 0 'none' (correctors.py:85-94), 1 'ald' (correctors.py:60-81) */
+  int corrector;          /* 0 'none' (correctors.py:85-94), 1 'ald' (correctors.py:60-81), 2 'langevin' (correctors.py:37-56:
+                             step size from batch-mean norms of score and noise) */
   int corrector_steps;
   int predictor;          /* 0 'none', 1 'reverse_diffusion' (predictors.py:56-65) */
   int probability_flow;   /* 1: fixed-step PF-ODE Euler step (sdes.py:130-135 with probability_flow=True), no noise */
@@ -66,6 +67,7 @@ typedef struct {
    * (model.py:307-310): in_scale 1, alpha 0, beta -1.  ncsnpp_v2 models: in_scale = c_in(t); 'score_matching': alpha =
    * c_skip(t), beta = c_out(t)*s(t); 'denoiser': alpha = -1/std(t)^2, beta = s(t)/std(t)^2; s = network_scaling. */
   const float* in_scale; const float* score_alpha; const float* score_beta;
+  float snr;              /* 'langevin' only: r in step = 2 (r * mean||z|| / mean||score||)^2 ('ald' has it folded into ald_eps) */
   int use_graph;          /* 1: capture one predictor-corrector step as a hipGraph and replay it N times */
 } sgmse_sampler_cfg;
 

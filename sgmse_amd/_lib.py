@@ -36,7 +36,7 @@ class SamplerCfgC(C.Structure):
                 ("t", C.POINTER(C.c_float)), ("dt", C.POINTER(C.c_float)), ("ald_eps", C.POINTER(C.c_float)),
                 ("ald_noise", C.POINTER(C.c_float)), ("G", C.POINTER(C.c_float)), ("G2", C.POINTER(C.c_float)),
                 ("in_scale", C.POINTER(C.c_float)), ("score_alpha", C.POINTER(C.c_float)), ("score_beta", C.POINTER(C.c_float)),
-                ("use_graph", C.c_int)]
+                ("snr", C.c_float), ("use_graph", C.c_int)]
 
 
 _P = C.c_void_p
@@ -243,7 +243,7 @@ class Context:
 
     def pc_sample(self, Y: torch.Tensor, table: Dict[str, torch.Tensor], *, theta: float, std1: float,
                   corrector: str, corrector_steps: int, predictor: str, probability_flow: bool, denoise: bool,
-                  noise: Optional[torch.Tensor], seed: int, use_graph: bool = True, affine=None):
+                  noise: Optional[torch.Tensor], seed: int, use_graph: bool = True, affine=None, snr: float = 0.0):
         """``affine``: optional (in_scale, score_alpha, score_beta) fp32 tensors of length N: the score wrapper of
         ScoreModel.forward's new-code branch (ncsnpp_v2); None = old-code branch (score = -F)."""
         Y = check_tensor(Y, "y", torch.complex64, self.device)
@@ -253,7 +253,8 @@ class Context:
         N = int(table["t"].numel())
         cfg = SamplerCfgC()
         cfg.N = N
-        cfg.corrector = {"none": 0, "ald": 1}[corrector]
+        cfg.corrector = {"none": 0, "ald": 1, "langevin": 2}[corrector]
+        cfg.snr = float(snr)
         cfg.corrector_steps = int(corrector_steps)
         cfg.predictor = {"none": 0, "reverse_diffusion": 1}[predictor]
         cfg.probability_flow = int(bool(probability_flow)); cfg.denoise = int(bool(denoise))

@@ -95,7 +95,7 @@ int sgmse_pc_sample(sgmse_ctx* ctx, const void* Y, void* out, int B, int F, int 
                     const void* noise, unsigned long long seed, int* nfe) {
   SG_ARG(ctx, Y && out && cfg && B > 0 && F > 0 && T > 0, "null pointer or non-positive shape");
   SG_ARG(ctx, cfg->N >= 1, "N must be >= 1");
-  SG_ARG(ctx, cfg->corrector == 0 || cfg->corrector == 1, "corrector must be none or ald");
+  SG_ARG(ctx, cfg->corrector >= 0 && cfg->corrector <= 2, "corrector must be none, ald or langevin");
   SG_ARG(ctx, cfg->predictor == 0 || cfg->predictor == 1, "predictor must be none or reverse_diffusion");
   SG_ARG(ctx, cfg->corrector == 0 || cfg->corrector_steps >= 1, "corrector_steps must be >= 1");
   return sg_guard(ctx, [&](sgmse::Engine& e) {
@@ -103,6 +103,7 @@ int sgmse_pc_sample(sgmse_ctx* ctx, const void* Y, void* out, int B, int F, int 
     s.N = cfg->N; s.corrector = cfg->corrector; s.corrector_steps = cfg->corrector_steps; s.predictor = cfg->predictor;
     s.probability_flow = cfg->probability_flow; s.denoise = cfg->denoise; s.theta = cfg->theta; s.std1 = cfg->std1;
     s.t = cfg->t; s.dt = cfg->dt; s.ald_eps = cfg->ald_eps; s.ald_noise = cfg->ald_noise; s.G = cfg->G; s.G2 = cfg->G2;
+    s.snr = cfg->snr;
     s.in_scale = cfg->in_scale; s.score_alpha = cfg->score_alpha; s.score_beta = cfg->score_beta;
     s.use_graph = cfg->use_graph;
     e.pc_sample((const float2*)Y, (float2*)out, B, F, T, s, (const float2*)noise, seed);

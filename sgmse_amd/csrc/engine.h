@@ -241,7 +241,8 @@ struct AttnW { const float *gw, *gb; ConvW qkv, proj; };
 
 struct SamplerCfg {
   int N = 30;
-  int corrector = 1;        // 0 none, 1 ald
+  int corrector = 1;        // 0 none, 1 ald, 2 langevin
+  float snr = 0.f;          // langevin only (ALD's snr is folded into the step table)
   int corrector_steps = 1;
   int predictor = 1;        // 0 none, 1 reverse_diffusion
   int probability_flow = 0;
@@ -326,7 +327,7 @@ class Engine {
                  unsigned long long seed) {
     require_ready();
     SG_REQUIRE(sc.N >= 1 && sc.t && sc.dt && sc.G && sc.G2, "pc_sample: step table missing");
-    SG_REQUIRE(sc.corrector == 0 || (sc.ald_eps && sc.ald_noise), "pc_sample: ALD table missing");
+    SG_REQUIRE(sc.corrector != 1 || (sc.ald_eps && sc.ald_noise), "pc_sample: ALD table missing");
     ensure_shape(B, F, T, sc.N);
     const size_t n = (size_t)B * F * T;
     // step table -> device
@@ -334,7 +335,7 @@ class Engine {
     for (int i = 0; i < sc.N; ++i) {
       float* r = &tab[(size_t)i * SC_STRIDE];
       r[SC_T] = sc.t[i]; r[SC_DT] = sc.dt[i]; r[SC_G] = sc.G[i]; r[SC_G2] = sc.G2[i];
-      if (sc.corrector) { r[SC_ALD_EPS] = sc.ald_eps[i]; r[SC_ALD_NOISE] = sc.ald_noise[i]; }
+      if (sc.corrector == 1) { r[SC_ALD_EPS] = sc.ald_eps[i]; r[SC_ALD_NOISE] = sc.ald_noise[i]; }
       tv[i] = sc.t[i];
     }
     const bool affine = sc.in_scale && sc.score_alpha && sc.score_beta;
@@ -359,6 +360,7 @@ class Engine {
     sa.x = sx_; sa.x_mean = sxm_; sa.y = Y; sa.score = sscore_; sa.noise = noise; sa.seed = seed;
     sa.table = step_table_; sa.step_ptr = step_ctr_; sa.theta = sc.theta; sa.std1 = sc.std1; sa.n = (int)n;
     sa.score_w = sc.probability_flow ? 0.5f : 1.0f;
+    sa.snr = sc.snr; sa.B = B; sa.per = F * T; sa.partial = lang_partial_; sa.lang = lang_scal_;
     const dim3 eg((unsigned)((n + 255) / 256));
 
     sa.draw_base = 0; sa.draw_per_step = 0;
@@ -374,7 +376,13 @@ class Engine {
         arena_.reset();
         run_forward(sx_, FT, Y, FT, sscore_, B, F, T, ctl);
         SamplerArgs a = sa; a.draw_base = 1 + cs; a.draw_per_step = draws_per_step;
-        DRT_LAUNCH(sampler_ald_kernel, eg, dim3(256), stream_, a);
+        if (sc.corrector == 2) {
+          DRT_LAUNCH(sampler_langevin_norms_kernel, dim3(LANG_NBLK, B), dim3(256), stream_, a);
+          DRT_LAUNCH(sampler_langevin_scalars_kernel, dim3(1), dim3(64), stream_, a);
+          DRT_LAUNCH(sampler_langevin_kernel, eg, dim3(256), stream_, a);
+        } else {
+          DRT_LAUNCH(sampler_ald_kernel, eg, dim3(256), stream_, a);
+        }
       }
       if (sc.predictor == 1) {
         arena_.reset();
@@ -386,7 +394,7 @@ class Engine {
     };
 
     GraphKey key{B, F, T, sc.corrector, ncorr, sc.predictor, sc.probability_flow + (affine ? 2 : 0), (const void*)Y, (const void*)noise, seed,
-                 sc.theta, draws_per_step};
+                 sc.theta + 1000.f * sc.snr * (sc.corrector == 2), draws_per_step};
     const bool want_graph = sc.use_graph && drt::graphs_supported();
     if (want_graph) {
       if (!graph_valid_ || !(key == graph_key_)) {
@@ -709,6 +717,9 @@ class Engine {
         samp_n_ = n;
       }
       if (!step_ctr_) step_ctr_ = static_cast<int*>(dev_alloc(256));
+      if (!lang_scal_) lang_scal_ = static_cast<float*>(dev_alloc(256));
+      if (lang_partial_) dev_free_owned(lang_partial_);
+      lang_partial_ = static_cast<float*>(dev_alloc((size_t)B * LANG_NBLK * 2 * 4));
       shape_B_ = B; shape_F_ = F; shape_T_ = T;
     }
     if (nrows > temb_rows_) {
@@ -1038,6 +1049,7 @@ class Engine {
   int B_ = 0, shape_B_ = 0, shape_F_ = 0, shape_T_ = 0;
   float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr, *sy_ = nullptr; size_t samp_n_ = 0;
   int* step_ctr_ = nullptr;
+  float *lang_partial_ = nullptr, *lang_scal_ = nullptr;
   float *temb_act_ = nullptr, *bias_table_ = nullptr, *step_table_ = nullptr, *tsteps_ = nullptr, *coef_table_ = nullptr; int temb_rows_ = 0;
   drt::graph_t graph_{}; bool graph_valid_ = false; GraphKey graph_key_{};
   int nfe_ = 0;

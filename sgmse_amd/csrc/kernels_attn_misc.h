@@ -299,6 +299,10 @@ struct SamplerArgs {
   int add_noise;
   float std1;               // prior: std(T=1)
   int n;                    // B*FT
+  // LangevinCorrector (correctors.py:44-56): step size from batch-mean norms
+  float snr; int B; int per;        // per = FT (elements per utterance)
+  float* partial;                   // [B][LANG_NBLK][2] partial sums of |grad|^2, |z|^2
+  float* lang;                      // [2]: step_size, sqrt(2*step_size)
 };
 
 __device__ __forceinline__ float2 sampler_noise(const SamplerArgs& p, int i, int draw) {
@@ -344,6 +348,64 @@ __global__ __launch_bounds__(256) void sampler_revdiff_kernel(SamplerArgs p) {
   } else {
     p.x[i] = xm;
   }
+}
+
+constexpr int LANG_NBLK = 64;
+
+// pass 1: per-utterance partial sums of |score|^2 and |z|^2.  grid = (LANG_NBLK, B)
+__global__ __launch_bounds__(256) void sampler_langevin_norms_kernel(SamplerArgs p) {
+  __shared__ float s_a[4];
+  __shared__ float s_b[4];
+  const int b = blockIdx.y;
+  const int step = *p.step_ptr;
+  const int draw = p.draw_base + step * p.draw_per_step;
+  float g2 = 0.f, z2 = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < p.per; i += LANG_NBLK * 256) {
+    const int e = b * p.per + i;
+    const float2 g = p.score[e];
+    const float2 z = sampler_noise(p, e, draw);
+    g2 += g.x * g.x + g.y * g.y;
+    z2 += z.x * z.x + z.y * z.y;
+  }
+  g2 = wave_sum(g2); z2 = wave_sum(z2);
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = g2; s_b[threadIdx.x >> 6] = z2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = p.partial + ((size_t)b * LANG_NBLK + blockIdx.x) * 2;
+    o[0] = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+    o[1] = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+  }
+}
+
+// pass 2 (one workgroup): grad_norm = mean_b ||score_b||, noise_norm = mean_b ||z_b||, step = 2 (snr noise_norm / grad_norm)^2
+__global__ __launch_bounds__(64) void sampler_langevin_scalars_kernel(SamplerArgs p) {
+  float gn = 0.f, zn = 0.f;
+  for (int b = threadIdx.x; b < p.B; b += 64) {
+    double g2 = 0.0, z2 = 0.0;
+    for (int k = 0; k < LANG_NBLK; ++k) { g2 += p.partial[((size_t)b * LANG_NBLK + k) * 2]; z2 += p.partial[((size_t)b * LANG_NBLK + k) * 2 + 1]; }
+    gn += sqrtf((float)g2); zn += sqrtf((float)z2);
+  }
+  gn = wave_sum(gn); zn = wave_sum(zn);
+  if (threadIdx.x == 0) {
+    gn /= (float)p.B; zn /= (float)p.B;
+    const float r = p.snr * zn / gn;
+    const float stepsz = r * r * 2.f;
+    p.lang[0] = stepsz;
+    p.lang[1] = sqrtf(stepsz * 2.f);
+  }
+}
+
+// pass 3: x_mean = x + step*score ; x = x_mean + z*sqrt(2 step)
+__global__ __launch_bounds__(256) void sampler_langevin_kernel(SamplerArgs p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const int step = *p.step_ptr;
+  const float eps = p.lang[0], ns = p.lang[1];
+  const float2 z = sampler_noise(p, i, p.draw_base + step * p.draw_per_step);
+  const float2 xv = p.x[i], g = p.score[i];
+  const float2 xm = make_float2(xv.x + eps * g.x, xv.y + eps * g.y);
+  p.x_mean[i] = xm;
+  p.x[i] = make_float2(xm.x + z.x * ns, xm.y + z.y * ns);
 }
 
 __global__ void step_set_kernel(int* step, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *step = v; }

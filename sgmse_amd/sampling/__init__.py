@@ -2,7 +2,7 @@
 
 ``get_pc_sampler`` returns a zero-argument callable producing ``(sample, nfe)`` like the reference.  When the score
 function is a ``ScoreModel`` with a HIP backbone, the SDE is OUVE and the predictor/corrector pair has fused kernels
-('reverse_diffusion' | 'none'  x  'ald' | 'none'), the whole N-step loop runs inside the HIP library
+('reverse_diffusion' | 'none'  x  'ald' | 'langevin' | 'none'), the whole N-step loop runs inside the HIP library
 (sgmse_pc_sample: one hipGraph-captured predictor-corrector step replayed N times, per-step constants from a device
 table, Philox or replayed noise).  Any other combination falls back to the reference's Python loop over the registry
 classes, with every score evaluation still running on the HIP network.
@@ -21,7 +21,7 @@ __all__ = ["PredictorRegistry", "CorrectorRegistry", "Predictor", "Corrector", "
            "get_ode_sampler"]
 
 _NATIVE_PRED = ("reverse_diffusion", "none")
-_NATIVE_CORR = ("ald", "none")
+_NATIVE_CORR = ("ald", "langevin", "none")
 
 
 def _native_engine(score_fn, y):
@@ -60,7 +60,7 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=Tru
                 out, nfe = ctx.pc_sample(y, table, theta=float(sde.theta), std1=std1, corrector=corrector_name,
                                          corrector_steps=corrector_steps, predictor=predictor_name,
                                          probability_flow=False, denoise=denoise, noise=noise, seed=s, use_graph=use_graph,
-                                         affine=affine)
+                                         affine=affine, snr=snr)
             return out, nfe
         return native_pc_sampler
 

@@ -93,7 +93,7 @@ def test_forward_matches_reference(hip, name):
     P.check_forward_golden(hip, name)
 
 
-@pytest.mark.parametrize("tag", ["pc_N4", "pc_N30", "pnone_N6", "pfode_N6"])
+@pytest.mark.parametrize("tag", ["pc_N4", "pc_N30", "pnone_N6", "pfode_N6", "lang_N4"])
 def test_samplers_match_reference(hip, tag):
     P.check_sampler_golden(hip, tag)
 
