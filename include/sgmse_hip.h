@@ -100,6 +100,15 @@ int sgmse_ncsnpp_forward(sgmse_ctx* ctx, const void* xy, const float* t, void* o
 int sgmse_pc_sample(sgmse_ctx* ctx, const void* Y, void* out, int B, int F, int T, const sgmse_sampler_cfg* cfg,
                     const void* noise, unsigned long long seed, int* nfe);
 
+/* -- get_sb_sampler(sde, model, y, ...)() (sampling/__init__.py:145-249), Schroedinger-bridge 'ode' and 'sde' samplers:
+ *    x_0 = y; for i in 0..N-1:  x <- w_prev[i] x + w_est[i] model(x, y, t[i]) + w_y[i] y + w_z[i] z_i.  Host arrays [N] computed
+ *    by the caller from SBVESDE._sigmas_alphas (sdes.py:276-288) with the reference's expressions (t = linspace(T, eps, N+1)[1:]);
+ *    'ode': w_z = 0; 'sde' (stochastic = 1): w_y = 0, one draw per step, noise complex64 [N][B][1][F][T] or NULL (Philox).
+ *    model = ScoreModel.forward with loss_type 'data_prediction': in_scale / score_alpha / score_beta as in sgmse_sampler_cfg. */
+int sgmse_sb_sample(sgmse_ctx* ctx, const void* Y, void* out, int B, int F, int T, int N, const float* t, const float* w_prev,
+                    const float* w_est, const float* w_y, const float* w_z, const float* in_scale, const float* score_alpha,
+                    const float* score_beta, int stochastic, const void* noise, unsigned long long seed, int use_graph, int* nfe);
+
 /* -- SpecsDataModule.stft / istft / spec_fwd / spec_back (data_module.py:162-188,212-218) ---------------------
  * sig fp32 [B][L] -> spec complex64 [B][n_fft/2+1][L/hop+1] (center=True, reflect pad, window fp32 [n_fft]). */
 int sgmse_stft(sgmse_ctx* ctx, const float* sig, const float* window, void* spec, int B, int L, int n_fft, int hop);

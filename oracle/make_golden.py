@@ -160,6 +160,32 @@ def main():
     assert r < 1e-4, r
     np.savez_compressed(os.path.join(OUT, "pfode_N6.npz"), y=y.numpy(), out=xt.numpy(), noise_seed=np.int64(7))
 
+    # ---- 3b. Schroedinger-bridge samplers: the reference's get_sb_sampler + SBVESDE + NCSNpp_v2 ---------------------
+    from sgmse.sdes import SBVESDE
+    cfg2 = NO.NetCfg.for_variant("ncsnpp_v2", nf=32)
+    P2 = synth.synth_params(cfg2, seed=0)
+    m2 = ref_model(cfg2, P2)
+
+    def ref_x0(x, yy, t):                      # model.py:284-304 with loss_type='data_prediction', c_in=c_out='1', c_skip='0'
+        return m2(x, yy, t)
+
+    for stype in ("ode", "sde"):
+        rs = SBVESDE(k=2.6, c=0.4, N=4)
+        noise = RefNoise(7)
+        torch.randn_like = noise
+        try:
+            x_ref, n = sampling.get_sb_sampler(rs, ref_x0, y=y, eps=1e-4, n_steps=4, sampler_type=stype)()
+        finally:
+            torch.randn_like = orig_randn_like
+        sb = SO.SBVE(2.6, 0.4, 4)
+        sv = SO.SBVE(2.6, 0.4, 4)
+        orc_model = lambda a, b, c: NO.score_fn_v2(P2, cfg2, sv, a, b, c, loss_type="data_prediction")
+        x_orc, _ = SO.sb_sample(sb, orc_model, y, SO.NoiseReplay(7), eps=1e-4, sampler_type=stype)
+        r = rel(x_orc, x_ref)
+        report.append((f"sb_{stype}_N4", r))
+        assert r < 1e-4, (stype, r)
+        np.savez_compressed(os.path.join(OUT, f"sb_{stype}_N4.npz"), y=y.numpy(), out=x_ref.numpy(), noise_seed=np.int64(7))
+
     # ---- 4. FIR resampling vs the reference's upfirdn2d_native ------------------------
     from sgmse.backbones.ncsnpp_utils import up_or_down_sampling as UD
     from sgmse.backbones.ncsnpp_utils.op.upfirdn2d import upfirdn2d_native

@@ -171,3 +171,55 @@ class NoiseReplay:
         z = torch.randn(like.shape, dtype=like.dtype, generator=self.gen)
         self.draws.append(z)
         return z
+
+
+@dataclass
+class SBVE:
+    """SBVESDE scalars (sdes.py:246-288)."""
+    k: float = 2.6
+    c: float = 0.4
+    N: int = 50
+    eps: float = 1e-8
+    T = 1
+
+    def sigmas_alphas(self, t):
+        alpha_t = torch.ones_like(t)
+        alpha_T = torch.ones_like(t)
+        sigma_t = torch.sqrt((self.c * (self.k ** (2 * t) - 1.0)) / (2 * torch.log(torch.tensor(self.k))))
+        sigma_T = torch.sqrt((self.c * (self.k ** (2 * self.T) - 1.0)) / (2 * torch.log(torch.tensor(self.k))))
+        alpha_bart = alpha_t / (alpha_T + self.eps)
+        sigma_bart = torch.sqrt(sigma_T ** 2 - sigma_t ** 2 + self.eps)
+        return sigma_t, sigma_T, sigma_bart, alpha_t, alpha_T, alpha_bart
+
+    def std(self, t):
+        sigma_t, sigma_T, sigma_bart, alpha_t, alpha_T, alpha_bart = self.sigmas_alphas(t)
+        return (alpha_t * sigma_bart * sigma_t) / (sigma_T + self.eps)
+
+
+def sb_sample(sde: SBVE, model: Callable, y: torch.Tensor, noise: Callable, *, eps=1e-4, sampler_type="ode"):
+    """get_sb_sampler, sampling/__init__.py:145-249 (both variants); ``model(x, y, t)`` is the data-prediction network."""
+    b4 = lambda v: v[:, None, None, None]
+    with torch.no_grad():
+        xt = y[:, [0]]
+        ts = torch.linspace(sde.T, eps, sde.N + 1)
+        sp, _, sbp, ap, _, _ = sde.sigmas_alphas(ts[0] * torch.ones(xt.shape[0]))
+        for t in ts[1:]:
+            time = t * torch.ones(xt.shape[0])
+            st, sT, sbt, at, aT, _ = sde.sigmas_alphas(time)
+            est = model(xt, y, time)
+            if sampler_type == "sde":
+                w_prev = at * st ** 2 / (ap * sp ** 2 + sde.eps)
+                tmp = 1 - st ** 2 / (sp ** 2 + sde.eps)
+                w_est = at * tmp
+                w_z = b4(at * st * torch.sqrt(tmp))
+                z = noise(xt)
+                if t == ts[-1]:
+                    w_z = 0.0
+                xt = b4(w_prev) * xt + b4(w_est) * est + w_z * z
+            else:
+                w_prev = at * st * sbt / (ap * sp * sbp + sde.eps)
+                w_est = at / (sT ** 2 + sde.eps) * (sbt ** 2 - sbp * st * sbt / (sp + sde.eps))
+                w_y = at / (aT * sT ** 2 + sde.eps) * (st ** 2 - sp * st * sbt / (sbp + sde.eps))
+                xt = b4(w_prev) * xt + b4(w_est) * est + b4(w_y) * y
+            sp, sbp, ap = st, sbt, at
+        return xt, sde.N

@@ -55,6 +55,7 @@ _SIGS = {
     "sgmse_param_count": (_I, [_P, C.POINTER(_LL)]),
     "sgmse_ncsnpp_forward": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "sgmse_pc_sample": (_I, [_P, _P, _P, _I, _I, _I, C.POINTER(SamplerCfgC), _P, C.c_ulonglong, C.POINTER(_I)]),
+    "sgmse_sb_sample": (_I, [_P, _P, _P, _I, _I, _I, _I] + [C.POINTER(_F)] * 8 + [_I, _P, C.c_ulonglong, _I, C.POINTER(_I)]),
     "sgmse_stft": (_I, [_P, _P, _P, _P, _I, _I, _I, _I]),
     "sgmse_istft": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "sgmse_spec_fwd": (_I, [_P, _P, _P, _LL, _I, _F, _F]),
@@ -296,6 +297,44 @@ class Context:
         else:
             run()
         self._keep["sampler"] = (noise, keep)   # the captured graph refers to the replayed-noise buffer
+        return out, nfe.value
+
+    def sb_sample(self, Y: torch.Tensor, table: Dict[str, torch.Tensor], *, stochastic: bool, noise: Optional[torch.Tensor],
+                  seed: int, affine=None, use_graph: bool = True):
+        """Schroedinger-bridge sampler; table: fp32 tensors t, w_prev, w_est, w_y, w_z of length N."""
+        Y = check_tensor(Y, "y", torch.complex64, self.device)
+        B, _, F_, T = Y.shape
+        N = int(table["t"].numel())
+        fp = lambda v: C.cast(v.data_ptr(), C.POINTER(_F))
+        keep = [table[k].detach().to("cpu", torch.float32).contiguous() for k in ("t", "w_prev", "w_est", "w_y", "w_z")]
+        aff = [None, None, None]
+        if affine is not None:
+            aff = [torch.as_tensor(v, dtype=torch.float32).detach().to("cpu").expand(N).contiguous() for v in affine]
+        if noise is not None:
+            noise = check_tensor(noise, "noise", torch.complex64, self.device)
+            if noise.shape[0] < N or tuple(noise.shape[1:]) != tuple(Y.shape):
+                raise ValueError(f"noise must be [{N},{B},1,{F_},{T}] complex64, got {tuple(noise.shape)}")
+        out = torch.empty_like(Y)
+        nfe = _I(0)
+
+        def run():
+            self.use_current_stream()
+            self.check(self.lib.sgmse_sb_sample(self.h, Y.data_ptr(), out.data_ptr(), B, F_, T, N, *[fp(v) for v in keep],
+                                                *[None if v is None else fp(v) for v in aff], int(bool(stochastic)), ptr(noise),
+                                                C.c_ulonglong(seed & (2 ** 64 - 1)), int(bool(use_graph)), C.byref(nfe)))
+
+        cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        if cur is not None and use_graph and cur.cuda_stream == 0:
+            side = self._keep.get("side_stream")
+            if side is None:
+                side = self._keep["side_stream"] = torch.cuda.Stream(self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                run()
+            cur.wait_stream(side)
+        else:
+            run()
+        self._keep["sb"] = (noise, keep, aff)
         return out, nfe.value
 
     def profile_forward(self, xy: torch.Tensor, t: torch.Tensor):

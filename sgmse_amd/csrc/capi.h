@@ -111,6 +111,18 @@ int sgmse_pc_sample(sgmse_ctx* ctx, const void* Y, void* out, int B, int F, int 
   });
 }
 
+int sgmse_sb_sample(sgmse_ctx* ctx, const void* Y, void* out, int B, int F, int T, int N, const float* t, const float* w_prev,
+                    const float* w_est, const float* w_y, const float* w_z, const float* in_scale, const float* score_alpha,
+                    const float* score_beta, int stochastic, const void* noise, unsigned long long seed, int use_graph, int* nfe) {
+  SG_ARG(ctx, Y && out && B > 0 && F > 0 && T > 0 && N >= 1, "null pointer or non-positive shape");
+  SG_ARG(ctx, t && w_prev && w_est && w_y && w_z, "step weights missing");
+  return sg_guard(ctx, [&](sgmse::Engine& e) {
+    e.sb_sample((const float2*)Y, (float2*)out, B, F, T, N, t, w_prev, w_est, w_y, w_z, in_scale, score_alpha, score_beta, stochastic,
+                (const float2*)noise, seed, use_graph);
+    if (nfe) *nfe = e.last_nfe();
+  });
+}
+
 int sgmse_stft(sgmse_ctx* ctx, const float* sig, const float* window, void* spec, int B, int L, int n_fft, int hop) {
   SG_ARG(ctx, sig && window && spec && B > 0 && L > 0, "null pointer or non-positive shape");
   return sg_guard(ctx, [&](sgmse::Engine& e) { e.op_stft(sig, window, (float2*)spec, B, L, n_fft, hop); });

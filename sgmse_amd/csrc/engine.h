@@ -412,6 +412,67 @@ class Engine {
     SG_CHECK(drt::memcpy_d2d(out, sc.denoise ? sxm_ : sx_, n * 8, stream_));
     nfe_ = sc.N * (ncorr + 1);   // the reference counts N*(corrector.n_steps+1) whatever the predictor (sampling/__init__.py:67)
   }
+  // get_sb_sampler(...)() (sampling/__init__.py:145-249): N steps of  x <- w_prev x + w_est model(x, y, t) + w_y y + w_z z,
+  // x_0 = y.  Host arrays [N]; coef (in_scale / alpha / beta, [N] each or all null) = the ScoreModel.forward wrapper.
+  void sb_sample(const float2* Y, float2* out, int B, int F, int T, int N, const float* t, const float* w_prev, const float* w_est,
+                 const float* w_y, const float* w_z, const float* in_scale, const float* alpha, const float* beta, int stochastic,
+                 const float2* noise, unsigned long long seed, int use_graph) {
+    require_ready();
+    SG_REQUIRE(N >= 1 && t && w_prev && w_est && w_y && w_z, "sb_sample: step table missing");
+    ensure_shape(B, F, T, N);
+    const size_t n = (size_t)B * F * T;
+    std::vector<float> tab((size_t)N * SC_STRIDE, 0.f), tv(N);
+    for (int i = 0; i < N; ++i) {
+      float* r = &tab[(size_t)i * SC_STRIDE];
+      r[SC_T] = t[i]; r[SB_WPREV] = w_prev[i]; r[SB_WEST] = w_est[i]; r[SB_WY] = w_y[i]; r[SB_WZ] = w_z[i];
+      tv[i] = t[i];
+    }
+    const bool affine = in_scale && alpha && beta;
+    SG_REQUIRE(affine || (!in_scale && !alpha && !beta), "sb_sample: give all three score-wrapper arrays or none");
+    if (affine) {
+      std::vector<float> cf((size_t)N * 4, 0.f);
+      for (int i = 0; i < N; ++i) { cf[4 * i] = in_scale[i]; cf[4 * i + 1] = alpha[i]; cf[4 * i + 2] = beta[i]; }
+      SG_CHECK(drt::memcpy_h2d(coef_table_, cf.data(), cf.size() * 4, stream_));
+    }
+    SG_CHECK(drt::memcpy_h2d(step_table_, tab.data(), tab.size() * 4, stream_));
+    SG_CHECK(drt::memcpy_h2d(tsteps_, tv.data(), tv.size() * 4, stream_));
+    SG_CHECK(drt::stream_sync(stream_));
+    compute_temb(tsteps_, N);
+    SG_CHECK(drt::memcpy_d2d(sy_, Y, n * 8, stream_));
+    SG_CHECK(drt::memcpy_d2d(sx_, Y, n * 8, stream_));          // x_0 = y
+    DRT_LAUNCH(step_set_kernel, dim3(1), dim3(64), stream_, step_ctr_, 0);
+
+    SamplerArgs sa{};
+    sa.x = sx_; sa.x_mean = sxm_; sa.y = sy_; sa.score = sscore_; sa.noise = noise; sa.seed = seed;
+    sa.table = step_table_; sa.step_ptr = step_ctr_; sa.n = (int)n; sa.add_noise = stochastic ? 1 : 0;
+    sa.draw_base = 0; sa.draw_per_step = 1;
+    const dim3 eg((unsigned)((n + 255) / 256));
+    FwdCtl ctl{bias_table_, 0, tot_temb_, step_ctr_, tsteps_, 0, 1, -1.0f};
+    if (affine) { ctl.coef = coef_table_; ctl.coef_bstride = 0; ctl.coef_sstride = 1; }
+    const long long FT = (long long)F * T;
+    auto step_body = [&]() {
+      arena_.reset();
+      run_forward(sx_, FT, sy_, FT, sscore_, B, F, T, ctl);
+      DRT_LAUNCH(sampler_sb_kernel, eg, dim3(256), stream_, sa);
+      DRT_LAUNCH(step_inc_kernel, dim3(1), dim3(64), stream_, step_ctr_);
+    };
+    GraphKey key{B, F, T, 100 + stochastic, 0, 0, affine ? 2 : 0, nullptr, (const void*)noise, seed, 0.f, 1};
+    if (use_graph && drt::graphs_supported()) {
+      if (!graph_valid_ || !(key == graph_key_)) {
+        invalidate_graph();
+        SG_CHECK(drt::stream_sync(stream_));
+        SG_CHECK(drt::graph_begin_capture(stream_));
+        step_body();
+        SG_CHECK(drt::graph_end_capture(stream_, &graph_));
+        graph_valid_ = true; graph_key_ = key;
+      }
+      for (int i = 0; i < N; ++i) SG_CHECK(drt::graph_launch(&graph_, stream_));
+    } else {
+      for (int i = 0; i < N; ++i) step_body();
+    }
+    SG_CHECK(drt::memcpy_d2d(out, sx_, n * 8, stream_));
+    nfe_ = N;
+  }
   int last_nfe() const { return nfe_; }
   size_t arena_bytes() const { return arena_cap_; }
 

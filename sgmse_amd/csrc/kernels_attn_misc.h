@@ -408,6 +408,26 @@ __global__ __launch_bounds__(256) void sampler_langevin_kernel(SamplerArgs p) {
   p.x[i] = make_float2(xm.x + z.x * ns, xm.y + z.y * ns);
 }
 
+// Schroedinger-bridge samplers (reference sampling/__init__.py:145-249): every step is the weighted sum
+//   x <- w_prev * x + w_est * estimate + w_y * y + w_z * z      (ODE: w_z = 0; SDE: w_y = 0, w_z = 0 on the last step)
+// with per-step weights from the device table (columns SB_*), estimate = ScoreModel.forward(x, y, t) (data prediction).
+enum { SB_WPREV = 2, SB_WEST = 3, SB_WY = 4, SB_WZ = 5 };
+
+__global__ __launch_bounds__(256) void sampler_sb_kernel(SamplerArgs p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const int step = *p.step_ptr;
+  const float* tb = p.table + (size_t)step * SC_STRIDE;
+  const float wp = tb[SB_WPREV], we = tb[SB_WEST], wy = tb[SB_WY], wz = tb[SB_WZ];
+  const float2 xv = p.x[i], ev = p.score[i], yv = p.y[i];
+  float2 r = make_float2(wp * xv.x + we * ev.x + wy * yv.x, wp * xv.y + we * ev.y + wy * yv.y);
+  if (p.add_noise) {
+    const float2 z = sampler_noise(p, i, p.draw_base + step * p.draw_per_step);
+    r.x += wz * z.x; r.y += wz * z.y;
+  }
+  p.x[i] = r;
+}
+
 __global__ void step_set_kernel(int* step, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *step = v; }
 __global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step = *step + 1; }
 

@@ -115,33 +115,41 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs p) {
   // task `it` of a stage: write item `it` of the staged registers (stage st_store) into LDS buffer NB, then refill the
   // same registers with item `it` of stage st_load.  Stage indices past the end are clamped by the caller (the extra
   // loads re-read the last stage, the extra stores land in a buffer nobody reads again), so there are no branches.
-  auto task = [&](auto itc, auto nbc, int st_store, int st_load) {
-    constexpr int IT = decltype(itc)::value, NB = decltype(nbc)::value;
+  // Every task is cut into NPART parts so that a part (<= ~12 instructions) fits in the shadow of the MFMAs around it.
+  constexpr int NPART = 4;
+  f32x4 tmp_o;   // transformed float4 of the vector item being staged (lives across the parts of one task)
+  auto task_part = [&](auto itc, auto partc, auto nbc, int st_store, int st_load) {
+    constexpr int IT = decltype(itc)::value, PART = decltype(partc)::value, NB = decltype(nbc)::value;
     float* din = NB ? s_in1 : s_in0;
     float* dw = NB ? s_w1 : s_w0;
     if constexpr (IT < NV) {
       const int cg = st_store * KH + cv[IT];
-      const float sc = s_sc[cg], sh = s_sh[cg];
       const bool ok = (okmask >> IT) & 1u;
-      f32x4 o;
-      o[0] = xf1(rv[IT][0], sc, sh, ok); o[1] = xf1(rv[IT][1], sc, sh, ok);
-      o[2] = xf1(rv[IT][2], sc, sh, ok); o[3] = xf1(rv[IT][3], sc, sh, ok);
-      *reinterpret_cast<f32x4*>(din + loff_v[IT]) = o;
-      rv[IT] = *reinterpret_cast<const f32x4*>(plane_of(st_load * KH + cv[IT]) + goff_v[IT]);
+      if constexpr (PART == 0) { const float sc = s_sc[cg], sh = s_sh[cg]; tmp_o[0] = xf1(rv[IT][0], sc, sh, ok); tmp_o[1] = xf1(rv[IT][1], sc, sh, ok); }
+      if constexpr (PART == 1) { const float sc = s_sc[cg], sh = s_sh[cg]; tmp_o[2] = xf1(rv[IT][2], sc, sh, ok); tmp_o[3] = xf1(rv[IT][3], sc, sh, ok); }
+      if constexpr (PART == 2) *reinterpret_cast<f32x4*>(din + loff_v[IT]) = tmp_o;
+      if constexpr (PART == 3) rv[IT] = *reinterpret_cast<const f32x4*>(plane_of(st_load * KH + cv[IT]) + goff_v[IT]);
     } else if constexpr (HALO && IT == NV) {
       const int cg = st_store * KH + ch;
-      din[loff_h] = xf1(rh, s_sc[cg], s_sh[cg], (okmask >> 31) & 1u);
-      rh = plane_of(st_load * KH + ch)[goff_h];
+      if constexpr (PART == 0) din[loff_h] = xf1(rh, s_sc[cg], s_sh[cg], (okmask >> 31) & 1u);
+      if constexpr (PART == 2) rh = plane_of(st_load * KH + ch)[goff_h];
     } else {
       constexpr int WI = IT - NV - (HALO ? 1 : 0);
       int idx = tid + 256 * WI;
       idx = idx < W_ELEMS / 4 ? idx : W_ELEMS / 4 - 1;
-      reinterpret_cast<f32x4*>(dw)[idx] = rw[WI];
-      rw[WI] = reinterpret_cast<const f32x4*>(wbase + (size_t)st_load * KH * TAPS * CO_T)[idx];
+      if constexpr (PART == 0) reinterpret_cast<f32x4*>(dw)[idx] = rw[WI];
+      if constexpr (PART == 2) rw[WI] = reinterpret_cast<const f32x4*>(wbase + (size_t)st_load * KH * TAPS * CO_T)[idx];
     }
   };
+  auto task = [&](auto itc, auto nbc, int st_store, int st_load) {   // whole task (prologue only)
+    task_part(itc, std::integral_constant<int, 0>{}, nbc, st_store, st_load);
+    task_part(itc, std::integral_constant<int, 1>{}, nbc, st_store, st_load);
+    task_part(itc, std::integral_constant<int, 2>{}, nbc, st_store, st_load);
+    task_part(itc, std::integral_constant<int, 3>{}, nbc, st_store, st_load);
+  };
 
-  // MFMAs of the stage in buffer CB, with the staging tasks interleaved after the MFMA groups 1..NTASK
+  // MFMAs of the stage in buffer CB; the FC*FP MFMAs of k-step s2 (1 <= s2 <= NTASK) are issued in NPART slices with
+  // part q of staging task s2-1 after slice q, each slice fenced with sched_barrier
   auto stage = [&](auto cbc, int st_store, int st_load) {
     constexpr int CB = decltype(cbc)::value;
     using NBc = std::integral_constant<int, CB ^ 1>;
@@ -156,16 +164,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs p) {
       for (int j = 0; j < FP; ++j) bb[slot][j] = si[j * RS + cp * 2 * PLANE + dy * RS + dx];
     };
     ld(0, 0);
+    constexpr int NM = FC * FP, SL = (NM + NPART - 1) / NPART;   // MFMAs per k-step, per slice
     auto group = [&](auto sc2) {
       constexpr int S2 = decltype(sc2)::value;
       if (S2 + 1 < NS) ld(S2 + 1, (S2 + 1) & 1);
+      auto slice = [&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
 #pragma unroll
-      for (int i = 0; i < FC; ++i)
-#pragma unroll
-        for (int j = 0; j < FP; ++j)
+        for (int m = Q * SL; m < (Q + 1) * SL && m < NM; ++m) {
+          const int i = m / FP, j = m % FP;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S2 & 1][i], bb[S2 & 1][j], acc[i][j], 0, 0, 0);
-      if constexpr (S2 >= 1 && S2 - 1 < NTASK) task(std::integral_constant<int, S2 - 1>{}, NBc{}, st_store, st_load);
-      __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (S2 >= 1 && S2 - 1 < NTASK) task_part(std::integral_constant<int, S2 - 1>{}, qc, NBc{}, st_store, st_load);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      slice(std::integral_constant<int, 0>{});
+      slice(std::integral_constant<int, 1>{});
+      slice(std::integral_constant<int, 2>{});
+      slice(std::integral_constant<int, 3>{});
     };
     // compile-time unrolled k-steps
     auto run = [&](auto self, auto sc2) -> void {

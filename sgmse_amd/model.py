@@ -238,8 +238,12 @@ class ScoreModel(nn.Module):
             return torch.cat(samples, dim=0), ns     # (the reference returns only the last mini-batch: model.py:389)
         return batched_sampling_fn
 
-    def get_sb_sampler(self, *a, **k):
-        raise NotImplementedError("the Schroedinger-bridge sampler is out of scope of this build")
+    def get_sb_sampler(self, sde, y, sampler_type="ode", N=None, **kwargs):
+        """reference model.py:392-397 (the passed ``sde`` only supplies the default N; the model's own SDE is used)."""
+        N = sde.N if N is None else N
+        sde = self.sde.copy()
+        sde.N = N if N is not None else sde.N
+        return sampling.get_sb_sampler(sde, self, y=y, sampler_type=sampler_type, **kwargs)
 
     # -- audio helpers (reference model.py:411-424) -----------------------------------------------------------
     def to_audio(self, spec, length=None):
@@ -279,6 +283,8 @@ class ScoreModel(nn.Module):
                 sampler = self.get_ode_sampler(Y, N=N, **kwargs)
             else:
                 raise ValueError("Invalid sampler type for SGMSE sampling: {}".format(sampler_type))
+        elif self.sde.__class__.__name__ == "SBVESDE":
+            sampler = self.get_sb_sampler(sde=self.sde, y=Y, sampler_type=self.sde.sampler_type, **kwargs)
         else:
             raise ValueError("Invalid SDE type for speech enhancement: {}".format(self.sde.__class__.__name__))
         sample, nfe = sampler()

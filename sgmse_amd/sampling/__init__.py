@@ -13,12 +13,12 @@ from typing import Optional
 
 import torch
 
-from ..sdes import OUVESDE
+from ..sdes import OUVESDE, SBVESDE
 from .correctors import Corrector, CorrectorRegistry
 from .predictors import Predictor, PredictorRegistry, ReverseDiffusionPredictor
 
 __all__ = ["PredictorRegistry", "CorrectorRegistry", "Predictor", "Corrector", "get_sampler", "get_pc_sampler",
-           "get_ode_sampler"]
+           "get_ode_sampler", "get_sb_sampler"]
 
 _NATIVE_PRED = ("reverse_diffusion", "none")
 _NATIVE_CORR = ("ald", "langevin", "none")
@@ -123,9 +123,53 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
     return ode_sampler
 
 
+def get_sb_sampler(sde, model, y, eps=1e-4, n_steps=50, sampler_type="ode", noise: Optional[torch.Tensor] = None,
+                   seed: Optional[int] = None, use_graph: bool = True, force_python_loop: bool = False, **kwargs):
+    """Schroedinger-bridge samplers (reference sampling/__init__.py:145-249): 'ode' (deterministic) and 'sde'.  With a
+    ScoreModel on a HIP backbone the N-step loop runs in the library (sgmse_sb_sample); otherwise the reference-style
+    Python loop below.  Returns a zero-argument callable -> (sample, n_steps) like the reference."""
+    if sampler_type not in ("ode", "sde"):
+        raise ValueError("Invalid type. Choose 'ode' or 'sde'.")
+    ctx = None if force_python_loop else (_native_engine(model, y) if isinstance(sde, SBVESDE) else None)
+    if ctx is not None:
+        table = sde.sb_step_table(eps, sampler_type, sde.N)
+        affine = model.score_affine(table["t"])
+
+        def native_sb_sampler():
+            s = seed if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+            with torch.no_grad():
+                out, _ = ctx.sb_sample(y[:, [0], :, :].contiguous(), table, stochastic=(sampler_type == "sde"), noise=noise, seed=s,
+                                       affine=affine, use_graph=use_graph)
+            return out, n_steps
+        return native_sb_sampler
+
+    def python_sb_sampler():
+        with torch.no_grad():
+            xt = y[:, [0], :, :]
+            ts = torch.linspace(sde.T, eps, sde.N + 1, device=y.device)
+            prev = sde._sigmas_alphas(ts[0] * torch.ones(xt.shape[0], device=xt.device))
+            for t in ts[1:]:
+                time = t * torch.ones(xt.shape[0], device=xt.device)
+                cur = sde._sigmas_alphas(time)
+                (sp, _, sbp, ap, _, _), (st, sT, sbt, at, aT, _) = prev, cur
+                est = model(xt, y, time)
+                b4 = lambda v: v[:, None, None, None]
+                if sampler_type == "sde":
+                    tmp = 1 - st ** 2 / (sp ** 2 + sde.eps)
+                    wz = 0.0 if t == ts[-1] else b4(at * st * torch.sqrt(tmp))
+                    xt = b4(at * st ** 2 / (ap * sp ** 2 + sde.eps)) * xt + b4(at * tmp) * est + wz * torch.randn_like(xt)
+                else:
+                    xt = (b4(at * st * sbt / (ap * sp * sbp + sde.eps)) * xt
+                          + b4(at / (sT ** 2 + sde.eps) * (sbt ** 2 - sbp * st * sbt / (sp + sde.eps))) * est
+                          + b4(at / (aT * sT ** 2 + sde.eps) * (st ** 2 - sp * st * sbt / (sbp + sde.eps))) * y)
+                prev = cur
+            return xt, n_steps
+    return python_sb_sampler
+
+
 def get_sampler(sampler_type, *args, **kwargs):
     if sampler_type == "pc":
         return get_pc_sampler(*args, **kwargs)
     if sampler_type == "ode":
         return get_ode_sampler(*args, **kwargs)
-    raise ValueError(f"Given sampler type {sampler_type} not supported (the Schroedinger-bridge sampler is out of scope).")
+    raise ValueError(f"Given sampler type {sampler_type} not supported")

@@ -5,7 +5,7 @@ Host-side mirror of reference sgmse/sdes.py:16-232 (SDERegistry, SDE, OUVESDE). 
 expressions the reference evaluates (so the constants are bit-identical) and shipped to the HIP sampler as a table;
 the tensor arithmetic of the loop runs in HIP kernels.  The tensor-valued methods (``sde``, ``marginal_prob``,
 ``prior_sampling``, ``discretize``, ``reverse``) are kept for API parity and for the generic Python sampler loop
-used with predictors/correctors that have no fused kernel.  SBVESDE (Schroedinger bridge) is out of scope.
+used with predictors/correctors that have no fused kernel.
 """
 import abc
 import warnings
@@ -169,3 +169,87 @@ class OUVESDE(SDE):
         g = self.sde(torch.zeros(1), torch.zeros(1), ts)[1]
         G = g * torch.sqrt(dt)
         return dict(t=ts, dt=dt, std=std, ald_eps=ald_eps, ald_noise=ald_noise, g=g, G=G, G2=G ** 2)
+
+
+@SDERegistry.register("sbve")
+class SBVESDE(SDE):
+    """Schroedinger bridge with a variance-exploding noise schedule (reference sdes.py:235-313; Jukic et al. 2024):
+    f = 0, g(t) = sqrt(c) k^t.  Only scalars are produced here; the sampler loop runs in the HIP library."""
+
+    @staticmethod
+    def add_argparse_args(parser):
+        parser.add_argument("--N", type=int, default=50, help="Number of discretisation steps (50).")
+        parser.add_argument("--k", type=float, default=2.6, help="Base of the diffusion coefficient (2.6).")
+        parser.add_argument("--c", type=float, default=0.4, help="Scale of the diffusion coefficient (0.4).")
+        parser.add_argument("--eps", type=float, default=1e-8, help="Numerical-stability constant (1e-8).")
+        parser.add_argument("--sampler_type", type=str, default="ode")
+        return parser
+
+    def __init__(self, k, c, N=50, eps=1e-8, sampler_type="ode", **ignored_kwargs):
+        super().__init__(N)
+        self.k, self.c, self.N, self.eps, self.sampler_type = k, c, N, eps, sampler_type
+
+    def copy(self):
+        return SBVESDE(self.k, self.c, N=self.N)       # like the reference (sdes.py:263-264): eps / sampler_type reset to defaults
+
+    @property
+    def T(self):
+        return 1
+
+    def sde(self, x, y, t):
+        return 0.0, torch.sqrt(torch.tensor(self.c)) * self.k ** t
+
+    def _sigmas_alphas(self, t):
+        alpha_t = torch.ones_like(t)
+        alpha_T = torch.ones_like(t)
+        logk2 = 2 * torch.log(torch.tensor(self.k))
+        sigma_t = torch.sqrt((self.c * (self.k ** (2 * t) - 1.0)) / logk2)
+        sigma_T = torch.sqrt((self.c * (self.k ** (2 * self.T) - 1.0)) / logk2)
+        alpha_bart = alpha_t / (alpha_T + self.eps)
+        sigma_bart = torch.sqrt(sigma_T ** 2 - sigma_t ** 2 + self.eps)
+        return sigma_t, sigma_T, sigma_bart, alpha_t, alpha_T, alpha_bart
+
+    def _mean(self, x0, y, t):
+        sigma_t, sigma_T, sigma_bart, alpha_t, alpha_T, alpha_bart = self._sigmas_alphas(t)
+        w_xt = alpha_t * sigma_bart ** 2 / (sigma_T ** 2 + self.eps)
+        w_yt = alpha_bart * sigma_t ** 2 / (sigma_T ** 2 + self.eps)
+        return _bshape(w_xt, x0) * x0 + _bshape(w_yt, y) * y
+
+    def _std(self, t):
+        sigma_t, sigma_T, sigma_bart, alpha_t, alpha_T, alpha_bart = self._sigmas_alphas(t)
+        return (alpha_t * sigma_bart * sigma_t) / (sigma_T + self.eps)
+
+    def marginal_prob(self, x0, y, t):
+        return self._mean(x0, y, t), self._std(t)
+
+    def prior_sampling(self, shape, y):
+        if shape != y.shape:
+            warnings.warn(f"Target shape {shape} does not match shape of y {y.shape}! Ignoring target shape.")
+        return y
+
+    def prior_logp(self, z):
+        raise NotImplementedError("prior_logp for SBVE SDE not yet implemented!")
+
+    def sb_step_table(self, eps: float, sampler_type: str, N: int = None):
+        """Per-step weights of get_sb_sampler (sampling/__init__.py:145-249), fp32 tensors of length N evaluated with the
+        reference's expressions on t = linspace(T, eps, N+1):  x <- w_prev x + w_est model(x, y, t) + w_y y + w_z z."""
+        N = self.N if N is None else N
+        ts = torch.linspace(self.T, eps, N + 1)
+        s, sT, sbar, a, aT, abar = self._sigmas_alphas(ts)
+        sp, sbp, ap = s[:-1], sbar[:-1], a[:-1]            # values at the previous time step
+        st, sbt, at, sTt, aTt = s[1:], sbar[1:], a[1:], sT, aT[1:]   # sigma_T is a 0-dim tensor (sdes.py:281-282)
+        if sampler_type == "sde":
+            w_prev = at * st ** 2 / (ap * sp ** 2 + self.eps)
+            tmp = 1 - st ** 2 / (sp ** 2 + self.eps)
+            w_est = at * tmp
+            w_z = at * st * torch.sqrt(tmp)
+            w_z[-1] = 0.0                                   # no noise on the last step (sampling/__init__.py:183-184)
+            w_y = torch.zeros_like(w_prev)
+        elif sampler_type == "ode":
+            w_prev = at * st * sbt / (ap * sp * sbp + self.eps)
+            w_est = at / (sTt ** 2 + self.eps) * (sbt ** 2 - sbp * st * sbt / (sp + self.eps))
+            w_y = at / (aTt * sTt ** 2 + self.eps) * (st ** 2 - sp * st * sbt / (sbp + self.eps))
+            w_z = torch.zeros_like(w_prev)
+        else:
+            raise ValueError("Invalid type. Choose 'ode' or 'sde'.")
+        return dict(t=ts[1:].clone(), w_prev=w_prev, w_est=w_est, w_y=w_y, w_z=w_z)

@@ -129,12 +129,12 @@ def check_forward_golden(dev, name, batch=None):
     assert rel_l2(out.cpu(), ref) < NET_TOL, name
 
 
-def make_model(cfg, dev, P=None, **kw):
+def make_model(cfg, dev, P=None, sde="ouve", **kw):
     from sgmse_amd.model import ScoreModel
     P = synth.synth_params(cfg, seed=0) if P is None else P
-    sde_kw = dict(theta=1.5, sigma_min=0.05, sigma_max=0.5)
+    sde_kw = dict(theta=1.5, sigma_min=0.05, sigma_max=0.5) if sde == "ouve" else {}
     sde_kw.update(kw)
-    m = ScoreModel(cfg.variant, "ouve", nf=cfg.nf, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks,
+    m = ScoreModel(cfg.variant, sde, nf=cfg.nf, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks,
                    attn_resolutions=cfg.attn_resolutions, image_size=cfg.image_size, progressive=cfg.progressive,
                    progressive_input=cfg.progressive_input, **sde_kw)
     m.dnn.load_state_dict(P, strict=True)
@@ -248,3 +248,24 @@ def check_sampler_v2(dev, loss_type, network_scaling, c_in, c_out, c_skip, N=2, 
     noise = torch.stack(rep.draws).to(dev)
     out, nfe = m.get_pc_sampler("reverse_diffusion", "ald", y.to(dev), N=N, snr=0.5, noise=noise, use_graph=use_graph)()
     assert nfe == nfe_ref and rel_l2(out.cpu(), ref) < SAMPLER_TOL
+
+
+def check_sb_golden(dev, stype, batch=None, use_graph=True):
+    """Schroedinger-bridge sampler ('ode' / 'sde', N=4) of an ncsnpp_v2 data-prediction model against the output of the
+    reference's own get_sb_sampler + SBVESDE + NCSNpp_v2 (fixture), with replayed noise for 'sde'."""
+    z = load(f"sb_{stype}_N4")
+    cfg = NO.NetCfg.for_variant("ncsnpp_v2", nf=32)
+    m, _ = make_model(cfg, dev, sde="sbve", k=2.6, c=0.4, N=4, loss_type="data_prediction")
+    y, ref = torch.from_numpy(z["y"]), torch.from_numpy(z["out"])
+    noise = replay_noise(y.shape, 4) if stype == "sde" else None
+    if batch is not None:
+        y, ref = y[:batch], ref[:batch]
+        noise = None if noise is None else noise[:, :batch]
+    sampler = m.get_sb_sampler(m.sde, y.to(dev), sampler_type=stype, n_steps=4,
+                               noise=None if noise is None else noise.contiguous().to(dev), use_graph=use_graph)
+    out, n = sampler()
+    assert n == 4 and rel_l2(out.cpu(), ref) < SAMPLER_TOL, stype
+    if batch is None:     # the reference-style Python loop over the HIP network agrees with the fused loop (deterministic variant)
+        if stype == "ode":
+            out2, _ = m.get_sb_sampler(m.sde, y.to(dev), sampler_type="ode", n_steps=4, force_python_loop=True)()
+            assert rel_l2(out2.cpu(), out.cpu()) < 1e-5

@@ -41,6 +41,10 @@ def test_conv_thin_output_on_padded_mfma_tile(emu):
     P.check_conv(emu, 2, 128, 4, 4, 8, 3, xform=True)
 
 
+def test_schroedinger_bridge_sampler_matches_reference(emu):
+    P.check_sb_golden(emu, "sde", batch=1)
+
+
 def test_sampler_langevin_corrector_against_oracle(emu):
     """LangevinCorrector couples the batch through mean norms (correctors.py:50-52): B = 2."""
     P.check_sampler_oracle(emu, "ncsnpp", N=1, corrector="langevin", snr=0.5, F_=256, T=64, B=2)

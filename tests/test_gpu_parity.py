@@ -109,6 +109,11 @@ def test_sampler_new_code_score_wrapper(hip, wrap):
     P.check_sampler_v2(hip, *wrap, N=2)
 
 
+@pytest.mark.parametrize("stype", ["ode", "sde"])
+def test_schroedinger_bridge_sampler_matches_reference(hip, stype):
+    P.check_sb_golden(hip, stype)
+
+
 def test_sampler_graph_equals_eager(hip):
     """The hipGraph-captured step replayed N times must equal the eager loop bit for bit (same kernels, same order)."""
     cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)

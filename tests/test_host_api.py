@@ -18,7 +18,7 @@ def test_registries_match_reference_names():
     from sgmse_amd.sdes import SDERegistry
     from sgmse_amd.sampling import PredictorRegistry, CorrectorRegistry
     assert set(BackboneRegistry.get_all_names()) >= {"ncsnpp", "ncsnpp_48k", "ncsnpp_v2"}
-    assert "ouve" in SDERegistry.get_all_names()
+    assert set(SDERegistry.get_all_names()) == {"ouve", "sbve"}
     assert set(PredictorRegistry.get_all_names()) == {"euler_maruyama", "reverse_diffusion", "none"}
     assert set(CorrectorRegistry.get_all_names()) == {"langevin", "ald", "none"}
     for reg in (BackboneRegistry, SDERegistry, PredictorRegistry, CorrectorRegistry):
@@ -66,6 +66,24 @@ def test_ouve_matches_oracle_scalars():
     s = OUVESDE(1.5, 0.05, 0.5, N=30)
     c = s.copy()
     assert (c.theta, c.sigma_min, c.sigma_max, c.N, c.sampler_type) == (1.5, 0.05, 0.5, 30, "pc") and s.T == 1
+
+
+def test_sbve_step_table_matches_oracle_loop():
+    """SBVESDE.sb_step_table (vectorised weights handed to the HIP loop) against the step-by-step oracle restatement of
+    get_sb_sampler, using a linear fake model so the weights are the only arithmetic."""
+    from sgmse_amd.sdes import SBVESDE
+    from oracle import sde_oracle as SO
+    y = torch.randn(1, 1, 4, 8, dtype=torch.complex64, generator=torch.Generator().manual_seed(0))
+    model = lambda x, yy, t: 0.5 * x + 0.25 * yy
+    for stype in ("ode", "sde"):
+        tab = SBVESDE(2.6, 0.4, N=6).sb_step_table(1e-4, stype)
+        rep = SO.NoiseReplay(5)
+        ref, _ = SO.sb_sample(SO.SBVE(2.6, 0.4, 6), model, y, rep, eps=1e-4, sampler_type=stype)
+        x = y.clone()
+        for i in range(6):
+            z = rep.draws[i] if stype == "sde" else 0.0
+            x = tab["w_prev"][i] * x + tab["w_est"][i] * model(x, y, None) + tab["w_y"][i] * y + tab["w_z"][i] * z
+        assert rel_l2(x, ref) < 1e-6, stype
 
 
 def test_generic_python_sampler_matches_oracle_with_fake_score():

@@ -101,3 +101,14 @@ def test_front_end_self_consistency(fc, L):
     assert rel_l2(FO.spec_back(FO.spec_fwd(S, fc), fc), S) < 1e-5
     Y = FO.pad_spec(FO.spec_fwd(S, fc)[None, :1], "zero_pad")
     assert Y.shape[-1] % 64 == 0
+
+
+@pytest.mark.parametrize("stype", ["ode", "sde"])
+def test_sb_sampler_matches_reference(stype):
+    z = load(f"sb_{stype}_N4")
+    cfg = NO.NetCfg.for_variant("ncsnpp_v2", nf=32)
+    P = synth.synth_params(cfg, seed=0)
+    sv = SO.SBVE(2.6, 0.4, 4)
+    model = lambda a, b, c: NO.score_fn_v2(P, cfg, sv, a, b, c, loss_type="data_prediction")
+    out, n = SO.sb_sample(SO.SBVE(2.6, 0.4, 4), model, torch.from_numpy(z["y"]), SO.NoiseReplay(7), eps=1e-4, sampler_type=stype)
+    assert n == 4 and rel_l2(out, z["out"]) < 1e-4
