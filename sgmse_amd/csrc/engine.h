@@ -264,6 +264,7 @@ class Engine {
   }
   ~Engine() {
     for (void* p : owned_) drt::free_dev(p);
+    for (void* p : wowned_) drt::free_dev(p);
     if (graph_valid_) drt::graph_destroy(&graph_);
   }
 
@@ -275,11 +276,14 @@ class Engine {
   const NetCfg& config() const { return cfg_; }
 
   void load_weights(const char* const* names, const void* const* ptrs, const long long* numels, int n, int on_device) {
+    invalidate_graph();            // a captured graph refers to the old weight buffers
+    weights_ready_ = false;
+    free_weight_allocs();
     auto manifest = param_manifest(cfg_);
     std::map<std::string, size_t> want;
     size_t total = 0;
     for (auto& kv : manifest) { want[kv.first] = kv.second; total += (kv.second + 63) / 64 * 64; }
-    float* blob = static_cast<float*>(dev_alloc(total * 4));
+    float* blob = static_cast<float*>(dev_alloc_w(total * 4));
     blob_ = blob; blob_elems_ = total;
     std::map<std::string, std::pair<const void*, long long>> given;
     for (int i = 0; i < n; ++i) given[names[i]] = {ptrs[i], numels[i]};
@@ -624,6 +628,19 @@ class Engine {
 
  private:
   // ---- memory helpers ------------------------------------------------------------------------------------------
+  // allocations that belong to the current weight set; released together when new weights are loaded (EMA swap, reload)
+  void* dev_alloc_w(size_t bytes) {
+    void* p = nullptr;
+    SG_CHECK(drt::malloc_dev(&p, bytes ? bytes : 256));
+    wowned_.push_back(p);
+    return p;
+  }
+  void free_weight_allocs() {
+    if (wowned_.empty()) return;
+    drt::stream_sync(stream_);
+    for (void* p : wowned_) drt::free_dev(p);
+    wowned_.clear();
+  }
   void* dev_alloc(size_t bytes) {
     void* p = nullptr;
     SG_CHECK(drt::malloc_dev(&p, bytes ? bytes : 256));
@@ -668,14 +685,14 @@ class Engine {
     if (pl.mfma) {
       c.co_t = pl.co_t;
       const size_t ne = packed_weight_elems(ks, cin, cout, pl.co_t);
-      float* pk = static_cast<float*>(dev_alloc(ne * 4));
+      float* pk = static_cast<float*>(dev_alloc_w(ne * 4));
       PackArgs pa{}; pa.src[0] = c.oihw; pa.nsrc = 1; pa.cout_per_src = cout; pa.io = 0; pa.cin = cin; pa.taps = ks * ks;
       pa.cout = cout; pa.co_t = pl.co_t; pa.dst = pk; pa.total = ne;
       DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, pa);
       c.packed = pk;
       if (pl.co_t > 32 && ks == 3) {
         const size_t ne32 = packed_weight_elems(ks, cin, cout, 32);
-        float* pk32 = static_cast<float*>(dev_alloc(ne32 * 4));
+        float* pk32 = static_cast<float*>(dev_alloc_w(ne32 * 4));
         PackArgs pb = pa; pb.co_t = 32; pb.dst = pk32; pb.total = ne32;
         DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne32 + 255) / 256)), dim3(256), stream_, pb);
         c.packed32 = pk32;
@@ -687,8 +704,8 @@ class Engine {
   // NIN weights W[cin][cout] (layers.py:549); nsrc of them concatenated along cout (fused q|k|v projection)
   ConvW make_nin(const std::string& pre, const int* which, int nsrc, int C) {
     ConvW c; c.ks = 1; c.cin = C; c.cout = nsrc * C;
-    float* tr = static_cast<float*>(dev_alloc((size_t)nsrc * C * C * 4));
-    float* bb = static_cast<float*>(dev_alloc((size_t)nsrc * C * 4));
+    float* tr = static_cast<float*>(dev_alloc_w((size_t)nsrc * C * C * 4));
+    float* bb = static_cast<float*>(dev_alloc_w((size_t)nsrc * C * 4));
     for (int s = 0; s < nsrc; ++s) {
       const std::string n = pre + "NIN_" + std::to_string(which[s]);
       DRT_LAUNCH(transpose_io_kernel, dim3((C * C + 255) / 256), dim3(256), stream_, Wp(n + ".W"), tr + (size_t)s * C * C, C, C);
@@ -699,7 +716,7 @@ class Engine {
     if (pl.mfma) {
       c.co_t = pl.co_t;
       const size_t ne = packed_weight_elems(1, C, c.cout, pl.co_t);
-      float* pk = static_cast<float*>(dev_alloc(ne * 4));
+      float* pk = static_cast<float*>(dev_alloc_w(ne * 4));
       PackArgs pa{}; pa.nsrc = nsrc; pa.cout_per_src = C; pa.io = 1; pa.cin = C; pa.taps = 1; pa.cout = c.cout; pa.co_t = pl.co_t;
       pa.dst = pk; pa.total = ne;
       for (int s = 0; s < nsrc; ++s) pa.src[s] = Wp(pre + "NIN_" + std::to_string(which[s]) + ".W");
@@ -744,7 +761,7 @@ class Engine {
     }
     tot_temb_ = off;
     n_dense_ = (int)descs.size();
-    dense_descs_ = static_cast<DenseDesc*>(dev_alloc(sizeof(DenseDesc) * descs.size()));
+    dense_descs_ = static_cast<DenseDesc*>(dev_alloc_w(sizeof(DenseDesc) * descs.size()));
     SG_CHECK(drt::memcpy_h2d(dense_descs_, descs.data(), sizeof(DenseDesc) * descs.size(), stream_));
     SG_CHECK(drt::stream_sync(stream_));
     check_launch();
@@ -1101,7 +1118,7 @@ class Engine {
   std::map<int, std::pair<const float*, const float*>> gn_;
   DenseDesc* dense_descs_ = nullptr; int n_dense_ = 0; int tot_temb_ = 0;
   bool weights_ready_ = false;
-  std::vector<void*> owned_;
+  std::vector<void*> owned_, wowned_;
   std::map<int, const float2*> twiddles_;
 
   Arena arena_; char* arena_base_ = nullptr; size_t arena_cap_ = 0;

@@ -269,3 +269,19 @@ def check_sb_golden(dev, stype, batch=None, use_graph=True):
         if stype == "ode":
             out2, _ = m.get_sb_sampler(m.sde, y.to(dev), sampler_type="ode", n_steps=4, force_python_loop=True)()
             assert rel_l2(out2.cpu(), out.cpu()) < 1e-5
+
+
+def check_weight_reload(dev):
+    """Parameters changed in place (what an EMA swap does) reach the engine after mark_weights_changed(); the old packed
+    buffers are released."""
+    cfg = NET_CASES["fwd_nf32"]
+    net, _ = make_backbone(cfg, dev)
+    z = load("fwd_nf32")
+    x, t = torch.from_numpy(z["x"])[:1].to(dev), torch.from_numpy(z["t"])[:1].to(dev)
+    a = net(x, t)
+    with torch.no_grad():
+        net.output_layer.weight.mul_(2.0)
+        net.output_layer.bias.mul_(2.0)
+    net.mark_weights_changed()
+    b = net(x, t)
+    assert torch.equal(b, 2.0 * a)

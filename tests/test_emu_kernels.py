@@ -86,6 +86,10 @@ def test_forward_matches_reference_ncsnpp(emu):
     P.check_forward_golden(emu, "fwd_nf32", batch=1)
 
 
+def test_weight_reload(emu):
+    P.check_weight_reload(emu)
+
+
 def test_forward_matches_reference_ncsnpp_v2(emu):
     P.check_forward_golden(emu, "fwd_v2_nf32")
 

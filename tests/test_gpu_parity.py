@@ -163,6 +163,40 @@ def test_enhance_end_to_end(hip):
     P.check_enhance(hip, L=8000, N=3)
 
 
+def test_weight_reload(hip):
+    P.check_weight_reload(hip)
+
+
+def test_long_utterance_forward_against_oracle(hip):
+    """10 s utterance: T = 1280 frames (attention over 16 x 80 = 1280 tokens), reduced-width network, vs the CPU oracle."""
+    cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
+    net, Pm = P.make_backbone(cfg, hip)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 2, 256, 1280, dtype=torch.complex64, generator=g) * 0.3
+    t = torch.tensor([0.8, 0.1])
+    with torch.no_grad():
+        ref = NO.ncsnpp_forward(Pm, cfg, x, t)
+    out = net(x.to(hip), t.to(hip))
+    assert rel_l2(out.cpu(), ref) < P.NET_TOL
+
+
+def test_repeated_sampler_calls_are_reproducible_and_shape_changes_are_handled(hip):
+    """Same seed -> same bits across calls (captured graph reused); a different batch size re-plans the arena and graph."""
+    cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
+    m, _ = P.make_model(cfg, hip)
+    y2 = synth.synth_spec(2, 256, 64, seed=3).to(hip)
+    a, _ = m.get_pc_sampler("reverse_diffusion", "ald", y2, N=2, snr=0.5, seed=5)()
+    b, _ = m.get_pc_sampler("reverse_diffusion", "ald", y2, N=2, snr=0.5, seed=5)()
+    assert torch.equal(a, b)
+    y3 = synth.synth_spec(3, 256, 128, seed=3).to(hip)
+    c, _ = m.get_pc_sampler("reverse_diffusion", "ald", y3, N=2, snr=0.5, seed=5)()
+    assert c.shape == y3.shape and torch.isfinite(torch.view_as_real(c)).all()
+    d, _ = m.get_pc_sampler("reverse_diffusion", "ald", y2, N=2, snr=0.5, seed=5)()
+    assert torch.equal(a, d)
+    e, _ = m.get_pc_sampler("reverse_diffusion", "ald", y2, N=2, snr=0.5, seed=6)()
+    assert not torch.equal(a, e)
+
+
 def test_full_size_forward_against_oracle(hip):
     """BASELINE config-1 shape: one evaluation of the 65.6 M-parameter network at [1,4,256,512] vs the CPU oracle."""
     cfg = NO.NetCfg.for_variant("ncsnpp")
