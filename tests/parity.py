@@ -268,7 +268,7 @@ def check_sb_golden(dev, stype, batch=None, use_graph=True):
     if batch is None:     # the reference-style Python loop over the HIP network agrees with the fused loop (deterministic variant)
         if stype == "ode":
             out2, _ = m.get_sb_sampler(m.sde, y.to(dev), sampler_type="ode", n_steps=4, force_python_loop=True)()
-            assert rel_l2(out2.cpu(), out.cpu()) < 1e-5
+            assert rel_l2(out2.cpu(), out.cpu()) < SAMPLER_TOL   # the bridge weights cancel catastrophically in fp32; GPU pow differs by ulps
 
 
 def check_weight_reload(dev):
