@@ -515,7 +515,7 @@ class Engine {
     DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C1), dim3(256), stream_, x, (const float*)nullptr, C1, 0, HW, stats);
     if (C2) DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C2), dim3(256), stream_, x2, (const float*)nullptr, C2, 0, HW, stats2);
     const int G = std::min(C / 4, 32);
-    DRT_LAUNCH(gn_finalize_kernel, dim3(B), dim3(256), stream_, (const float*)stats, C1, 1, (const float*)stats2, C2, 1, gamma, beta, G,
+    DRT_LAUNCH(gn_finalize_kernel, dim3(G, B), dim3(256), stream_, (const float*)stats, C1, 1, (const float*)stats2, C2, 1, gamma, beta, G,
                HW, 1e-6f, sc, sh);
     DRT_LAUNCH(gn_apply_kernel, dim3((HW + 1023) / 1024, B * C), dim3(256), stream_, x, x2, C1, C2, HW, (const float*)sc,
                (const float*)sh, act, out);
@@ -862,7 +862,7 @@ class Engine {
     if (!dry_) {
       tock();
       const int G = std::min(C / 4, 32);
-      DRT_LAUNCH(gn_finalize_kernel, dim3(B_), dim3(256), stream_, st[0], a.C, nsub[0], st[1], b ? b->C : 0, nsub[1], gamma, beta, G,
+      DRT_LAUNCH(gn_finalize_kernel, dim3(G, B_), dim3(256), stream_, st[0], a.C, nsub[0], st[1], b ? b->C : 0, nsub[1], gamma, beta, G,
                  HW, 1e-6f, *sc, *sh);
       tick(TC_GN, 8.0 * B_ * ((double)a.C * nsub[0] + (b ? (double)b->C * nsub[1] : 0.0)), 1);
     }
@@ -876,17 +876,25 @@ class Engine {
     Tensor o = new_tensor(w.cout, a.H, a.W);
     const int kc_ = (w.ks == 3) ? 8 : 32;
     const bool use_mfma = w.packed && (b == nullptr || a.C % kc_ == 0);
-    // tile choice: the wide (128/64-channel) tile, except on the coarse U-Net levels (<= 8 wide tiles per image: 16x32 and
-    // below at 4 s), where 32-channel tiles give 4x more workgroups.  Decided per IMAGE, not per batch, so that the
-    // arithmetic (incl. the order of the GroupNorm partial sums) of one utterance never depends on its batch.
-    int co_t = w.co_t;
-    const int rows_ = a.H >= 8 ? 8 : 4;
-    if (use_mfma && w.packed32) {
-      const long per_image = (long)((a.H + rows_ - 1) / rows_) * ((a.W + 31) / 32) * ((w.cout + w.co_t - 1) / w.co_t);
-      if (per_image <= 8) co_t = 32;
+    // tile choice: the most efficient tile (widest channel block, 8 rows) that still gives the chip enough workgroups
+    // (tile_min_blocks_, ~4 per CU), falling back towards 32 channels x 4 rows for the coarse U-Net levels and for small
+    // batches.  All tile shapes accumulate every output in the same order and emit the same per-row GroupNorm partials
+    // (kernels_conv.h), so the choice -- and with it the batch size -- never changes a result bit.
+    int co_t = w.co_t, rows_ = a.H >= 8 ? 8 : 4;
+    if (use_mfma) {
+      const int cand_co[2] = {w.co_t, w.packed32 ? 32 : w.co_t};
+      long best = -1;
+      bool done = false;
+      for (int ci = 0; ci < 2 && !done; ++ci)
+        for (int rows = (a.H >= 8 ? 8 : 4); rows >= 4 && !done; rows -= 4) {
+          if (ci == 1 && cand_co[1] == cand_co[0]) break;
+          const long nblk = (long)B_ * ((a.H + rows - 1) / rows) * ((a.W + 31) / 32) * ((w.cout + cand_co[ci] - 1) / cand_co[ci]);
+          if (nblk > best) { best = nblk; co_t = cand_co[ci]; rows_ = rows; }
+          if (nblk >= tile_min_blocks_) done = true;
+        }
     }
     if (emit_stats && use_mfma && fuse_gn_stats_) {
-      o.nsub = conv_plan_nsub(co_t, rows_, a.H, a.W);
+      o.nsub = conv_plan_nsub(a.H, a.W);
       o.st = arena_.alloc((size_t)B_ * w.cout * o.nsub * 2);
     }
     if (dry_) return o;
@@ -1123,6 +1131,7 @@ class Engine {
 
   Arena arena_; char* arena_base_ = nullptr; size_t arena_cap_ = 0;
   bool dry_ = false;
+  long tile_min_blocks_ = [] { const char* e = getenv("SGMSE_TILE_MIN_BLOCKS"); return e ? atol(e) : 1024L; }();       // measurement knob
   bool fuse_gn_stats_ = [] { const char* e = getenv("SGMSE_FUSE_GN_STATS"); return !(e && e[0] == '0'); }();   // measurement knob
   int B_ = 0, shape_B_ = 0, shape_F_ = 0, shape_T_ = 0;
   float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr, *sy_ = nullptr; size_t samp_n_ = 0;

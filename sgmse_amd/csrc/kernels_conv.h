@@ -44,7 +44,9 @@ struct ConvArgs {
   float* out;
   int Cout, B, H, W;
   // optional GroupNorm statistics of the stored output, fused into the epilogue: per (b, co, sub-tile) partial
-  // {sum, sum of squares}; sub-tile = (tile index in the image) * WP + (pixel-wave index).  Deterministic (no atomics).
+  // {sum, sum of squares}; sub-tile = one image row x one 32-pixel segment, index y * ceil(W/32) + x/32 -- the unit every
+  // tile shape of this kernel family decomposes into, so the partials (and everything computed from them) do not depend
+  // on which tile shape a launch used.  Deterministic (no atomics); stats_nsub = H * ceil(W/32).
   float* stats_out;
   int stats_nsub;
   // measurement-only ablation switches for sgmse_bench_conv (results are then WRONG on purpose): bit 0 skip the
@@ -109,9 +111,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
       }
       bv[r] = t;
     }
-    float ssum[16], ssq[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
     // residual: the 16 values of fragment row j+1 are loaded (independent, unconditional, clamped addresses) before the
     // adds and stores of row j -- issued one by one behind their dependent add + store, the residual read cost 11 % of the
     // kernel (profiles/r01_conv_ablation.txt); a whole-column batch (FP*16 registers) spills
@@ -136,32 +135,70 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
     for (int j = 0; j < FP; ++j) {
       if (has_res && j + 1 < FP) load_res(j + 1, (j + 1) & 1);
       const int y = y0 + wp * FP + j;
-      if (y < H && x < W) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co_base + (r & 3) + 8 * (r >> 2);
-          if (co < p.Cout) {
-            const size_t o = ((size_t)(b * p.Cout + co) * H + y) * W + x;
-            float v = (acc[i][j][r] + bv[r] + rr[j & 1][r]) * p.out_scale;
-            if (!(p.ablate & 1)) p.out[o] = v;
-            else if (v == 12345.678f) p.out[o] = v;   // keeps the value live without storing
-            ssum[r] += v;
-            ssq[r] += v * v;
-          }
-        }
-      }
-    }
-    if (p.stats_out) {   // wave-uniform
-      const int sub = (ty * tiles_x + tx) * T::WP + wp;
+      const bool pok = y < H && x < W;
+      float sv[16], sq[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float a1 = ssum[r], a2 = ssq[r];
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) { a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
         const int co = co_base + (r & 3) + 8 * (r >> 2);
-        if (l31 == 0 && co < p.Cout) {
-          float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + sub) * 2;
-          so[0] = a1; so[1] = a2;
+        float v = (acc[i][j][r] + bv[r] + rr[j & 1][r]) * p.out_scale;
+        const bool ok = pok && co < p.Cout;
+        if (ok) {
+          const size_t o = ((size_t)(b * p.Cout + co) * H + y) * W + x;
+          if (!(p.ablate & 1)) p.out[o] = v;
+          else if (v == 12345.678f) p.out[o] = v;   // keeps the value live without storing
+        }
+        v = ok ? v : 0.f;
+        sv[r] = v;
+        sq[r] = v * v;
+      }
+      if (p.stats_out && y < H) {   // wave-uniform: GroupNorm partials of this 32-pixel row segment
+        // butterfly over the 32 lanes of a half-wave: at every step a lane keeps half of its registers and receives the
+        // partner's copy of that half, so after 4 steps it owns ONE register summed over 16 lanes and after the 5th over
+        // all 32 (16 shuffles per quantity instead of 5 x 16); the owned register is (l31 >> 1) & 15
+        float a1[8], a2[8];
+        {
+          const bool up = l31 & 16;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float s1 = up ? sv[k] : sv[k + 8], s2 = up ? sq[k] : sq[k + 8];
+            a1[k] = (up ? sv[k + 8] : sv[k]) + __shfl_xor(s1, 16);
+            a2[k] = (up ? sq[k + 8] : sq[k]) + __shfl_xor(s2, 16);
+          }
+        }
+        float b1[4], b2[4];
+        {
+          const bool up = l31 & 8;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float s1 = up ? a1[k] : a1[k + 4], s2 = up ? a2[k] : a2[k + 4];
+            b1[k] = (up ? a1[k + 4] : a1[k]) + __shfl_xor(s1, 8);
+            b2[k] = (up ? a2[k + 4] : a2[k]) + __shfl_xor(s2, 8);
+          }
+        }
+        float c1[2], c2[2];
+        {
+          const bool up = l31 & 4;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float s1 = up ? b1[k] : b1[k + 2], s2 = up ? b2[k] : b2[k + 2];
+            c1[k] = (up ? b1[k + 2] : b1[k]) + __shfl_xor(s1, 4);
+            c2[k] = (up ? b2[k + 2] : b2[k]) + __shfl_xor(s2, 4);
+          }
+        }
+        float d1, d2;
+        {
+          const bool up = l31 & 2;
+          const float s1 = up ? c1[0] : c1[1], s2 = up ? c2[0] : c2[1];
+          d1 = (up ? c1[1] : c1[0]) + __shfl_xor(s1, 2);
+          d2 = (up ? c2[1] : c2[0]) + __shfl_xor(s2, 2);
+        }
+        d1 += __shfl_xor(d1, 1);
+        d2 += __shfl_xor(d2, 1);
+        const int r = (l31 >> 1) & 15;
+        const int co = co_base + (r & 3) + 8 * (r >> 2);
+        if ((l31 & 1) == 0 && co < p.Cout) {
+          float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)y * tiles_x + tx) * 2;
+          so[0] = d1; so[1] = d2;
         }
       }
     }
@@ -483,9 +520,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs p) {
 // Which MFMA tile a layer uses.  co_t in {32,64,128}; rows in {8,4}.
 struct ConvPlan { int co_t; int rows; bool mfma; };
 inline int conv_plan_wp(int co_t) { return co_t == 32 ? 4 : 2; }            // pixel-waves per workgroup (ConvTile::WP)
-inline int conv_plan_nsub(int co_t, int rows, int H, int W) {                 // statistics sub-tiles per image
-  return ((H + rows - 1) / rows) * ((W + 31) / 32) * conv_plan_wp(co_t);
-}
+inline int conv_plan_nsub(int H, int W) { return H * ((W + 31) / 32); }     // statistics sub-tiles per image (tile-independent)
 
 inline ConvPlan choose_conv_plan(int ks, int cin, int cout, int H, int W) {
   ConvPlan pl{0, 0, false};

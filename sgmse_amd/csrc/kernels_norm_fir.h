@@ -52,29 +52,41 @@ __global__ __launch_bounds__(256) void gn_chan_stats_kernel(const float* src1, c
 
 // Per-(b,c) totals come as `nsub` partial {sum, sumsq} pairs per channel (nsub = 1 from gn_chan_stats_kernel, the number
 // of statistics sub-tiles when a convolution epilogue produced them); the two sources of a virtual concat may differ.
-// grid = B blocks of 256 threads.
+// grid = (G, B): one workgroup per group.  The partials of a group's channels are contiguous per source, so the 256 threads
+// stream them coalesced (fixed thread -> element map and a fixed fp64 tree: deterministic), then thread c < cpg writes the
+// folded coefficients of channel g*cpg + c.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* st1, int C1, int nsub1, const float* st2, int C2, int nsub2,
                                                           const float* gamma, const float* beta, int G, int HW, float eps,
                                                           float* scale, float* shift) {
-  __shared__ double s_s[512];
-  __shared__ double s_q[512];
-  const int b = blockIdx.x, C = C1 + C2;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float* st = (c < C1) ? st1 + (size_t)(b * C1 + c) * nsub1 * 2 : st2 + (size_t)(b * C2 + (c - C1)) * nsub2 * 2;
-    const int n = (c < C1) ? nsub1 : nsub2;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < n; ++k) { s += (double)st[2 * k]; q += (double)st[2 * k + 1]; }
-    s_s[c] = s; s_q[c] = q;
+  __shared__ double s_s[256];
+  __shared__ double s_q[256];
+  const int g = blockIdx.x, b = blockIdx.y, C = C1 + C2, cpg = C / G;
+  const int c_lo = g * cpg, c_hi = c_lo + cpg;
+  double s = 0.0, q = 0.0;
+  // source 1 covers channels [c_lo, min(c_hi, C1)), source 2 the rest (a group may straddle the concat boundary)
+  const int a_hi = c_hi < C1 ? c_hi : C1;
+  if (c_lo < a_hi) {
+    const float* base = st1 + ((size_t)b * C1 + c_lo) * nsub1 * 2;
+    const int n = (a_hi - c_lo) * nsub1;
+    for (int i = threadIdx.x; i < n; i += 256) { s += (double)base[2 * i]; q += (double)base[2 * i + 1]; }
   }
+  const int b_lo = c_lo > C1 ? c_lo : C1;
+  if (b_lo < c_hi) {
+    const float* base = st2 + ((size_t)b * C2 + (b_lo - C1)) * nsub2 * 2;
+    const int n = (c_hi - b_lo) * nsub2;
+    for (int i = threadIdx.x; i < n; i += 256) { s += (double)base[2 * i]; q += (double)base[2 * i + 1]; }
+  }
+  s_s[threadIdx.x] = s; s_q[threadIdx.x] = q;
   __syncthreads();
-  const int cpg = C / G;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int g = c / cpg;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < cpg; ++k) { s += s_s[g * cpg + k]; q += s_q[g * cpg + k]; }
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m) { s_s[threadIdx.x] += s_s[threadIdx.x + m]; s_q[threadIdx.x] += s_q[threadIdx.x + m]; }
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < cpg) {
+    const int c = c_lo + threadIdx.x;
     const double n = (double)cpg * (double)HW;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
+    const double mean = s_s[0] / n;
+    double var = s_q[0] / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float a = gamma[c] * rstd;
