@@ -2,6 +2,7 @@
 #pragma once
 #include "kernels_conv.h"
 #include "kernels_conv_pipe.h"
+#include "kernels_conv1x1.h"
 
 #ifndef SGMSE_CONV_PIPE_DEFAULT
 #define SGMSE_CONV_PIPE_DEFAULT 1
@@ -12,6 +13,7 @@ namespace sgmse {
 // Measurement knob SGMSE_CONV_VARIANT (also the `variant` argument of sgmse_bench_conv):
 //   bit 0: operand prefetch off (compiler-ordered LDS reads)   bit 1: element-wise instead of float4 input staging
 //   bit 2: toggle the software-pipelined kernel (kernels_conv_pipe.h) for the 128 x 256 tiles
+//   bit 3: 1x1 convolutions through the LDS-tiled kernels instead of the streaming kernel (kernels_conv1x1.h)
 inline int conv_variant() {
   static int v = [] { const char* e = getenv("SGMSE_CONV_VARIANT"); return e ? atoi(e) : 0; }();
   return v;
@@ -37,6 +39,13 @@ inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant)
 }
 
 inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1) {
+  if (ks == 1 && pl.co_t == 128 && !((variant < 0 ? conv_variant() : variant) & 8)) {
+    const int tiles = a.B * ((a.H + pl.rows - 1) / pl.rows) * ((a.W + 31) / 32);
+    dim3 grid(tiles, a.Cout / 128, 1);
+    if (pl.rows == 8) DRT_LAUNCH((conv1x1_stream_kernel<2>), grid, dim3(256), st, a);
+    else DRT_LAUNCH((conv1x1_stream_kernel<1>), grid, dim3(256), st, a);
+    return;
+  }
 #define SGMSE_CONV_CASE(KS_, CO_, ROWS_, WC_, FC_, FP_) \
   if (ks == KS_ && pl.co_t == CO_ && pl.rows == ROWS_) { launch_conv_mfma_t<KS_, WC_, FC_, FP_>(a, st, variant); return; }
   SGMSE_CONV_CASE(3, 128, 8, 2, 2, 4)

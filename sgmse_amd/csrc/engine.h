@@ -877,7 +877,7 @@ class Engine {
     const int kc_ = (w.ks == 3) ? 8 : 32;
     const bool use_mfma = w.packed && (b == nullptr || a.C % kc_ == 0);
     // tile choice: the most efficient tile (widest channel block, 8 rows) that still gives the chip enough workgroups
-    // (tile_min_blocks_, ~4 per CU), falling back towards 32 channels x 4 rows for the coarse U-Net levels and for small
+    // (tile_min_blocks_, 2 per CU), falling back towards 32 channels x 4 rows for the coarse U-Net levels and for small
     // batches.  All tile shapes accumulate every output in the same order and emit the same per-row GroupNorm partials
     // (kernels_conv.h), so the choice -- and with it the batch size -- never changes a result bit.
     int co_t = w.co_t, rows_ = a.H >= 8 ? 8 : 4;
@@ -1131,7 +1131,7 @@ class Engine {
 
   Arena arena_; char* arena_base_ = nullptr; size_t arena_cap_ = 0;
   bool dry_ = false;
-  long tile_min_blocks_ = [] { const char* e = getenv("SGMSE_TILE_MIN_BLOCKS"); return e ? atol(e) : 1024L; }();       // measurement knob
+  long tile_min_blocks_ = [] { const char* e = getenv("SGMSE_TILE_MIN_BLOCKS"); return e ? atol(e) : 512L; }();        // measurement knob (profiles/r01_tile_sweep.txt)
   bool fuse_gn_stats_ = [] { const char* e = getenv("SGMSE_FUSE_GN_STATS"); return !(e && e[0] == '0'); }();   // measurement knob
   int B_ = 0, shape_B_ = 0, shape_F_ = 0, shape_T_ = 0;
   float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr, *sy_ = nullptr; size_t samp_n_ = 0;

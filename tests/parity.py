@@ -129,6 +129,30 @@ def check_forward_golden(dev, name, batch=None):
     assert rel_l2(out.cpu(), ref) < NET_TOL, name
 
 
+def check_tile_independence(dev, name, batch=None):
+    """The conv tile shape follows the workgroup count (batch size, U-Net level), so it must never change a bit of the
+    result: widest tiles everywhere vs narrowest tiles everywhere (SGMSE_TILE_MIN_BLOCKS is read at engine creation)."""
+    cfg = NET_CASES[name]
+    z = load(name)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    if batch is not None:
+        x, t = x[:batch], t[:batch]
+    outs = []
+    old = os.environ.get("SGMSE_TILE_MIN_BLOCKS")
+    try:
+        for m in ("1", "1000000000"):
+            os.environ["SGMSE_TILE_MIN_BLOCKS"] = m
+            net, _ = make_backbone(cfg, dev)
+            outs.append(net(x.to(dev), t.to(dev)).cpu())
+    finally:
+        if old is None:
+            os.environ.pop("SGMSE_TILE_MIN_BLOCKS", None)
+        else:
+            os.environ["SGMSE_TILE_MIN_BLOCKS"] = old
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[0], torch.from_numpy(z["out"])[:len(x)]) < NET_TOL
+
+
 def make_model(cfg, dev, P=None, sde="ouve", **kw):
     from sgmse_amd.model import ScoreModel
     P = synth.synth_params(cfg, seed=0) if P is None else P

@@ -24,7 +24,7 @@ def test_conv_direct(emu, shape):
     P.check_conv(emu, *shape, direct=True)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 8])
 def test_conv_kernel_variants(emu, variant):
     """Every selectable structure of the MFMA convolution (operand prefetch on/off, float4 / element-wise staging, the
     software-pipelined kernel) computes the same convolution."""
@@ -52,6 +52,14 @@ def test_sampler_langevin_corrector_against_oracle(emu):
 
 def test_sampler_48k_variant_against_oracle(emu):
     P.check_sampler_oracle(emu, "ncsnpp_48k", N=1, snr=0.33, F_=192, T=64, B=1)
+
+
+def test_conv1x1_streaming_kernel(emu):
+    """Cout % 128 == 0 routes 1x1 convolutions to conv1x1_stream_kernel (8-row and 4-row tiles, ragged edges, concat)."""
+    P.check_conv(emu, 1, 64, 128, 9, 33, 1)
+    P.check_conv(emu, 2, 96, 256, 5, 40, 1, xform=True)
+    P.check_conv(emu, 1, 160, 128, 16, 20, 1, dual=64, xform=True)
+    P.check_conv(emu, 1, 32, 128, 1, 1, 1)
 
 
 def test_conv_concat_and_fused_groupnorm_silu(emu):
@@ -84,6 +92,10 @@ def test_attention(emu, shape):
 
 def test_forward_matches_reference_ncsnpp(emu):
     P.check_forward_golden(emu, "fwd_nf32", batch=1)
+
+
+def test_conv_tile_shape_never_changes_a_bit(emu):
+    P.check_tile_independence(emu, "fwd_nf32", batch=1)
 
 
 def test_weight_reload(emu):

@@ -24,7 +24,7 @@ def test_conv_mfma(hip, shape):
     P.check_conv(hip, *shape)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 8])
 def test_conv_kernel_variants(hip, variant):
     import os, subprocess, sys
     from conftest import HIP_LIB, ROOT
@@ -55,6 +55,16 @@ def test_conv_mfma_fused_groupnorm_statistics_path(hip):
 @pytest.mark.parametrize("shape", [(2, 4, 128, 32, 40, 3), (2, 128, 4, 32, 40, 3), (1, 4, 256, 16, 20, 1), (1, 24, 20, 7, 9, 3)])
 def test_conv_direct(hip, shape):
     P.check_conv(hip, *shape, direct=True)
+
+
+def test_conv1x1_streaming_kernel(hip):
+    """Cout % 128 == 0 routes 1x1 convolutions to conv1x1_stream_kernel (8-row and 4-row tiles, ragged edges, concat)."""
+    P.check_conv(hip, 1, 64, 128, 9, 33, 1)
+    P.check_conv(hip, 2, 96, 256, 5, 40, 1, xform=True)
+    P.check_conv(hip, 1, 160, 128, 16, 20, 1, dual=64, xform=True)
+    P.check_conv(hip, 1, 32, 128, 1, 1, 1)
+    P.check_conv(hip, 2, 256, 128, 256, 256, 1, dual=128, xform=True)
+    P.check_conv(hip, 1, 512, 256, 64, 64, 1, dual=256)
 
 
 def test_conv_concat_and_fused_groupnorm_silu(hip):
@@ -223,6 +233,10 @@ def test_full_size_batch_independence(hip):
         assert torch.equal(net(x[i:i + 1].contiguous(), t[i:i + 1].contiguous()), full[i:i + 1])
     perm = torch.tensor([2, 0, 1], device=hip)
     assert torch.equal(net(x[perm].contiguous(), t[perm].contiguous()), full[perm])
+
+
+def test_conv_tile_shape_never_changes_a_bit(hip):
+    P.check_tile_independence(hip, "fwd_nf32")
 
 
 def test_error_behaviour(hip):

@@ -22,6 +22,15 @@ if has bench; then echo "== bench"; timeout 900 python bench.py --steps ${BENCH_
 for v in ${BENCH_VARIANTS:-}; do echo "== bench SGMSE_CONV_VARIANT=$v"; SGMSE_CONV_VARIANT=$v timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_v$v.log 2>gpurun_out/bench_v$v.err; cat gpurun_out/bench_v$v.log | cut -c1-200; python -c "
 import json,sys
 d=json.loads(open('gpurun_out/bench_v$v.log').read().strip().splitlines()[-1]); print('variant $v', d['value'], d['roofline']['achieved'], {k:v['ms'] for k,v in d['kernel_classes_one_eval'].items()})"; done
+if has sweep; then
+  echo "== tile_min_blocks sweep (short sampler, N=6)"
+  for b in ${SWEEP_BATCHES:-1 4 32}; do for m in ${SWEEP_MINBLK:-256 512 1024 2048}; do
+    SGMSE_TILE_MIN_BLOCKS=$m timeout 300 python bench.py --batch $b --N 6 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/sweep_b${b}_m$m.log 2>/dev/null
+    python -c "
+import json
+d=json.loads(open('gpurun_out/sweep_b${b}_m$m.log').read().strip().splitlines()[-1]); print('batch $b min_blocks $m ms_per_step', round(d['ms_per_step'],1), {k:round(v['ms'],2) for k,v in d['kernel_classes_one_eval'].items()})"
+  done; done 2>&1 | tee gpurun_out/sweep.txt
+fi
 if has hbm; then
   echo "== HBM traffic of the dominant kernel (FETCH_SIZE / WRITE_SIZE passes; rocprofv3 --pmc segfaults on the full bench command)"
   rm -rf gpurun_out/hbm
