@@ -134,8 +134,11 @@ int sgmse_op_conv2d(sgmse_ctx* ctx, const float* x, const float* w_oihw, const f
 /* act(GroupNorm(min(C/4,32), C, eps=1e-6)(cat[x, x2])) (layerspp.py:219,243); act: 0 none, 1 SiLU.  synchronises */
 int sgmse_op_groupnorm(sgmse_ctx* ctx, const float* x, const float* gamma, const float* beta, float* out, int B, int C,
                        int H, int W, int act, const float* x2, int C2);
-/* upsample_2d / downsample_2d with k=(1,3,3,1), factor 2 (up_or_down_sampling.py:195-257); x fp32 [BC][H][W] */
-int sgmse_op_fir(sgmse_ctx* ctx, const float* x, float* out, int BC, int H, int W, int up);
+/* upsample_2d / downsample_2d with k=(1,3,3,1), factor 2 (up_or_down_sampling.py:195-257); x fp32 [BC][H][W].
+ * Optional fused producer as inside the network: out = FIR(act(x * in_scale[bc] + in_shift[bc])) (in_scale NULL: none;
+ * in_act 1: SiLU), and with out_raw != NULL also out_raw = FIR(x) from the same pass (layerspp.py:243-262). */
+int sgmse_op_fir(sgmse_ctx* ctx, const float* x, float* out, int BC, int H, int W, int up, const float* in_scale,
+                 const float* in_shift, int in_act, float* out_raw);
 /* attention core of AttnBlockpp (layerspp.py:82-88): qkv fp32 [B][3C][S] -> out fp32 [B][C][S] */
 int sgmse_op_attention(sgmse_ctx* ctx, const float* qkv, float* out, int B, int C, int S);
 

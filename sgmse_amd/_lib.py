@@ -63,7 +63,7 @@ _SIGS = {
     "sgmse_upfirdn2d": (_I, [_P, _P, _P, _P] + [_I] * 13),
     "sgmse_op_conv2d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _P, _I]),
     "sgmse_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I]),
-    "sgmse_op_fir": (_I, [_P, _P, _P, _I, _I, _I, _I]),
+    "sgmse_op_fir": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "sgmse_op_attention": (_I, [_P, _P, _P, _I, _I, _I]),
     "sgmse_profile_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(_I)]),
     "sgmse_bench_conv": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),

@@ -168,9 +168,10 @@ int sgmse_op_groupnorm(sgmse_ctx* ctx, const float* x, const float* gamma, const
   return sg_guard(ctx, [&](sgmse::Engine& e) { e.op_groupnorm(x, gamma, beta, out, B, C, H, W, act, x2, C2); });
 }
 
-int sgmse_op_fir(sgmse_ctx* ctx, const float* x, float* out, int BC, int H, int W, int up) {
+int sgmse_op_fir(sgmse_ctx* ctx, const float* x, float* out, int BC, int H, int W, int up, const float* in_scale,
+                 const float* in_shift, int in_act, float* out_raw) {
   SG_ARG(ctx, x && out && BC > 0 && H > 0 && W > 0, "null pointer or non-positive shape");
-  return sg_guard(ctx, [&](sgmse::Engine& e) { e.op_fir(x, out, BC, H, W, up); });
+  return sg_guard(ctx, [&](sgmse::Engine& e) { e.op_fir(x, out, BC, H, W, up, in_scale, in_shift, in_act, out_raw); });
 }
 
 int sgmse_op_attention(sgmse_ctx* ctx, const float* qkv, float* out, int B, int C, int S) {

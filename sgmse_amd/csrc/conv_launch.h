@@ -14,6 +14,7 @@ namespace sgmse {
 //   bit 0: operand prefetch off (compiler-ordered LDS reads)   bit 1: element-wise instead of float4 input staging
 //   bit 2: toggle the software-pipelined kernel (kernels_conv_pipe.h) for the 128 x 256 tiles
 //   bit 3: 1x1 convolutions through the LDS-tiled kernels instead of the streaming kernel (kernels_conv1x1.h)
+//   bit 4: 64-channel chunks in the streaming 1x1 kernel
 inline int conv_variant() {
   static int v = [] { const char* e = getenv("SGMSE_CONV_VARIANT"); return e ? atoi(e) : 0; }();
   return v;
@@ -39,12 +40,19 @@ inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant)
 }
 
 inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1) {
-  if (ks == 1 && pl.co_t == 128 && !((variant < 0 ? conv_variant() : variant) & 8)) {
-    const int tiles = a.B * ((a.H + pl.rows - 1) / pl.rows) * ((a.W + 31) / 32);
-    dim3 grid(tiles, a.Cout / 128, 1);
-    if (pl.rows == 8) DRT_LAUNCH((conv1x1_stream_kernel<2>), grid, dim3(256), st, a);
-    else DRT_LAUNCH((conv1x1_stream_kernel<1>), grid, dim3(256), st, a);
-    return;
+  const int v = variant < 0 ? conv_variant() : variant;
+  if (ks == 1 && pl.co_t == 128 && !(v & 8)) {
+    // streaming kernel chunk: 32 channels, or 64 with bit 4 (one wave = 128 co x 32 px of one row; an 8-row-per-workgroup
+    // shape with two pixel fragments per wave needs > 256 registers and spills)
+    const int kc = (v & 16) ? 64 : 32;
+    const int Cin = a.C1 + a.C2;
+    if (Cin % kc == 0 && (a.src2 == nullptr || a.C1 % kc == 0)) {
+      const int tiles = a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32);
+      dim3 grid(tiles, a.Cout / 128, 1);
+      if (kc == 64) DRT_LAUNCH((conv1x1_stream_kernel<1, 64>), grid, dim3(256), st, a);
+      else DRT_LAUNCH((conv1x1_stream_kernel<1, 32>), grid, dim3(256), st, a);
+      return;
+    }
   }
 #define SGMSE_CONV_CASE(KS_, CO_, ROWS_, WC_, FC_, FP_) \
   if (ks == KS_ && pl.co_t == CO_ && pl.rows == ROWS_) { launch_conv_mfma_t<KS_, WC_, FC_, FP_>(a, st, variant); return; }

@@ -524,10 +524,10 @@ class Engine {
     free_tmp(stats); free_tmp(sc); free_tmp(sh);
   }
 
-  void op_fir(const float* x, float* out, int BC, int H, int W, int up) {
-    FirArgs fa{x, out, nullptr, nullptr, 0, BC, H, W, nullptr};
-    if (up) DRT_LAUNCH(fir_up2_kernel, dim3((H * W + 255) / 256, BC), dim3(256), stream_, fa);
-    else DRT_LAUNCH(fir_down2_kernel, dim3(((H / 2) * (W / 2) + 255) / 256, BC), dim3(256), stream_, fa);
+  void op_fir(const float* x, float* out, int BC, int H, int W, int up, const float* in_scale, const float* in_shift, int in_act,
+              float* out_raw) {
+    FirArgs fa{x, out, in_scale, in_shift, in_act, BC, H, W, out_raw};
+    launch_fir(fa, up);
     check_launch();
   }
 
@@ -920,6 +920,17 @@ class Engine {
     return o;
   }
 
+  void launch_fir(const FirArgs& fa, bool up) {
+    const int H = fa.H, W = fa.W, BC = fa.BC;
+    if (fir_use_tiled(W) && !fir_scalar_) {
+      if (up) DRT_LAUNCH(fir_up2_tiled_kernel, dim3(((W + 63) / 64) * ((H + 7) / 8), BC), dim3(256), stream_, fa);
+      else DRT_LAUNCH(fir_down2_tiled_kernel, dim3(((W / 2 + 63) / 64) * ((H / 2 + 7) / 8), BC), dim3(256), stream_, fa);
+    } else {
+      if (up) DRT_LAUNCH(fir_up2_kernel, dim3((H * W + 255) / 256, BC), dim3(256), stream_, fa);
+      else DRT_LAUNCH(fir_down2_kernel, dim3(((H / 2) * (W / 2) + 255) / 256, BC), dim3(256), stream_, fa);
+    }
+  }
+
   // FIR x2 / /2 of `a` through the fused producer `xf`; with `raw` also FIR(a) itself from the same pass
   Tensor fir(const Tensor& a, bool up, const Xform& xf, Tensor* raw = nullptr) {
     Tensor o = up ? new_tensor(a.C, a.H * 2, a.W * 2) : new_tensor(a.C, a.H / 2, a.W / 2);
@@ -927,8 +938,7 @@ class Engine {
     if (dry_) return o;
     FirArgs fa{a.p, o.p, xf.scale, xf.shift, xf.act, B_ * a.C, a.H, a.W, raw ? raw->p : nullptr};
     tock();
-    if (up) DRT_LAUNCH(fir_up2_kernel, dim3((a.H * a.W + 255) / 256, B_ * a.C), dim3(256), stream_, fa);
-    else DRT_LAUNCH(fir_down2_kernel, dim3(((a.H / 2) * (a.W / 2) + 255) / 256, B_ * a.C), dim3(256), stream_, fa);
+    launch_fir(fa, up);
     tick(TC_FIR, 4.0 * B_ * (double)a.C * (a.H * a.W + (raw ? 2.0 : 1.0) * o.H * o.W));
     return o;
   }
@@ -1132,6 +1142,7 @@ class Engine {
   Arena arena_; char* arena_base_ = nullptr; size_t arena_cap_ = 0;
   bool dry_ = false;
   long tile_min_blocks_ = [] { const char* e = getenv("SGMSE_TILE_MIN_BLOCKS"); return e ? atol(e) : 512L; }();        // measurement knob (profiles/r01_tile_sweep.txt)
+  bool fir_scalar_ = [] { const char* e = getenv("SGMSE_FIR_SCALAR"); return e && e[0] == '1'; }();                     // measurement knob
   bool fuse_gn_stats_ = [] { const char* e = getenv("SGMSE_FUSE_GN_STATS"); return !(e && e[0] == '0'); }();   // measurement knob
   int B_ = 0, shape_B_ = 0, shape_F_ = 0, shape_T_ = 0;
   float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr, *sy_ = nullptr; size_t samp_n_ = 0;

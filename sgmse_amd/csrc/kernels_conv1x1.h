@@ -18,9 +18,9 @@
 
 namespace sgmse {
 
-template <int FP>
+template <int FP, int KC>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs p) {
-  constexpr int FC = 4, KC = 32, NSTEP = KC / 2, CO_T = 128;
+  constexpr int FC = 4, NSTEP = KC / 2, CO_T = 128;
   using T = ConvTile<1, 1, FC, FP, 1>;
   static_assert(T::CO_T == CO_T && T::ROWS == 4 * FP, "tile");
   __shared__ float s_w0[KC * CO_T];
@@ -67,12 +67,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const float* wbase = p.w + (size_t)co_blk * Cin * CO_T;
-  constexpr int NW4 = KC * CO_T / 4 / 256;   // float4 weight items per thread and chunk (4)
+  constexpr int NW4 = KC * CO_T / 4 / 256;   // float4 weight items per thread and chunk
   float xb[NSTEP][FP], xn[NSTEP][FP];
   f32x4 rw[NW4];
 
   // channel plane of (chunk base c0, k-step s, this lane's k half) in the virtual concat [src1 | src2]; a chunk never
-  // straddles the sources (C1 % 32 == 0 is required by the launcher)
+  // straddles the sources (C1 % KC == 0 is required by the launcher)
   auto load_x = [&](int c0, float (&dst)[NSTEP][FP]) {
     const bool first = c0 < p.C1;
     const float* base = first ? p.src1 + ((size_t)b * p.C1 + c0 + kh) * HW : p.src2 + ((size_t)b * p.C2 + (c0 - p.C1) + kh) * HW;

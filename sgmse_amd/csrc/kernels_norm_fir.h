@@ -195,6 +195,135 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(FirArgs p) {
   if (p.out_raw) fir_up2_emit(vr, p.out_raw + off, Wo);
 }
 
+// LDS-tiled forms of the two FIR resamplers for the wide U-Net levels (W % 4 == 0, W >= 64).  The per-pixel kernels
+// above evaluate the fused producer (GroupNorm affine + SiLU) once per tap -- 16x (down) / 9x (up) per input element --
+// and fetch with stride-2 addresses; they ran at ~15 % of the HBM rate (profiles/r01_bench_b32_kernel_stats.csv).
+// Here a workgroup stages its input tile once with aligned float4 loads, applies the producer once per element, and
+// the taps read LDS as aligned b64 pairs.
+struct FirTileDown { static constexpr int TO_H = 8, TO_W = 64, IR = 2 * TO_H + 2, RS = 136; };   // LDS col = gx - (2*ox0 - 4)
+struct FirTileUp { static constexpr int TI_H = 8, TI_W = 64, IR = TI_H + 2, RS = 72; };          // LDS col = gx - (ix0 - 4)
+
+template <class TT, int ICOLS>
+__device__ __forceinline__ void fir_stage_tile(const FirArgs& p, const float* plane, int gy0, int gx0, float a, float s,
+                                               float* sx, float* sr, bool want_raw) {
+  // rows gy0 .. gy0+IR-1; interior columns gx0 .. gx0+ICOLS-1 at LDS column 4; halo columns gx0-1 (col 3), gx0+ICOLS
+  constexpr int Q = ICOLS / 4;
+  const bool xf = p.in_scale != nullptr;
+  for (int it = threadIdx.x; it < TT::IR * Q; it += 256) {
+    const int r = it / Q, q = it - r * Q;
+    const int gy = gy0 + r, gx = gx0 + 4 * q;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f}, t = v;
+    if (gy >= 0 && gy < p.H && gx < p.W) {      // W % 4 == 0: a float4 is inside or outside as a whole
+      v = *reinterpret_cast<const f32x4*>(plane + (size_t)gy * p.W + gx);
+      t = v;
+      if (xf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float u = v[e] * a + s; t[e] = p.in_act ? silu_f(u) : u; }
+      }
+    }
+    *reinterpret_cast<f32x4*>(sx + r * TT::RS + 4 + 4 * q) = t;
+    if (want_raw) *reinterpret_cast<f32x4*>(sr + r * TT::RS + 4 + 4 * q) = v;
+  }
+  for (int it = threadIdx.x; it < TT::IR * 2; it += 256) {
+    const int r = it >> 1, side = it & 1;
+    const int gy = gy0 + r, gx = side ? gx0 + ICOLS : gx0 - 1;
+    float v = 0.f, t = 0.f;
+    if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+      v = plane[(size_t)gy * p.W + gx];
+      t = v;
+      if (xf) { float u = v * a + s; t = p.in_act ? silu_f(u) : u; }
+    }
+    const int c = side ? 4 + ICOLS : 3;
+    sx[r * TT::RS + c] = t;
+    if (want_raw) sr[r * TT::RS + c] = v;
+  }
+}
+
+// grid = (ceil(Wo/64) * ceil(Ho/8), BC); thread -> output column ox (64) and the output row pair 2*rp, 2*rp+1
+__device__ __forceinline__ void fir_down2_tile_emit(const float* s, int rp, int oxl, float* out, int Wo, bool row1) {
+  using TT = FirTileDown;
+  float h[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const float* row = s + (4 * rp + r) * TT::RS + 2 * oxl + 2;      // taps at columns 2*oxl+3 .. 2*oxl+6
+    const float2 p0 = *reinterpret_cast<const float2*>(row), p1 = *reinterpret_cast<const float2*>(row + 2),
+                 p2 = *reinterpret_cast<const float2*>(row + 4);
+    h[r] = 0.125f * p0.y + 0.375f * p1.x + 0.375f * p1.y + 0.125f * p2.x;
+  }
+  out[0] = 0.125f * h[0] + 0.375f * h[1] + 0.375f * h[2] + 0.125f * h[3];
+  if (row1) out[Wo] = 0.125f * h[2] + 0.375f * h[3] + 0.375f * h[4] + 0.125f * h[5];
+}
+
+__global__ __launch_bounds__(256) void fir_down2_tiled_kernel(FirArgs p) {
+  using TT = FirTileDown;
+  __shared__ float sx[TT::IR * TT::RS];
+  __shared__ float sr[TT::IR * TT::RS];
+  const int Ho = p.H / 2, Wo = p.W / 2;
+  const int tiles_x = (Wo + TT::TO_W - 1) / TT::TO_W;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int bc = blockIdx.y;
+  const float* plane = p.src + (size_t)bc * p.H * p.W;
+  float a = 1.f, s = 0.f;
+  if (p.in_scale) { a = p.in_scale[bc]; s = p.in_shift[bc]; }
+  const int ox0 = tx * TT::TO_W, oy0 = ty * TT::TO_H;
+  const bool raw = p.out_raw != nullptr;
+  fir_stage_tile<TT, 2 * TT::TO_W>(p, plane, 2 * oy0 - 1, 2 * ox0, a, s, sx, sr, raw);
+  __syncthreads();
+  const int oxl = threadIdx.x & 63, rp = threadIdx.x >> 6;
+  const int ox = ox0 + oxl, oy = oy0 + 2 * rp;
+  if (ox >= Wo || oy >= Ho) return;
+  const size_t o = (size_t)bc * Ho * Wo + (size_t)oy * Wo + ox;
+  fir_down2_tile_emit(sx, rp, oxl, p.out + o, Wo, oy + 1 < Ho);
+  if (raw) fir_down2_tile_emit(sr, rp, oxl, p.out_raw + o, Wo, oy + 1 < Ho);
+}
+
+// grid = (ceil(W/64) * ceil(H/8), BC); thread -> input pixel pair (jx, jx+1) of input row iy -> 2 x 4 outputs
+__device__ __forceinline__ void fir_up2_tile_emit(const float* s, int iyl, int jxl, float* out, int Wo) {
+  using TT = FirTileUp;
+  float he[3][2], ho[3][2];     // horizontal polyphase results of the three input rows, for the two input pixels
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float* row = s + (iyl + r) * TT::RS + jxl + 2;              // columns jxl+3 .. jxl+6 = pixels jx-1 .. jx+2
+    const float2 p0 = *reinterpret_cast<const float2*>(row), p1 = *reinterpret_cast<const float2*>(row + 2),
+                 p2 = *reinterpret_cast<const float2*>(row + 4);
+    he[r][0] = 0.25f * p0.y + 0.75f * p1.x;  ho[r][0] = 0.75f * p1.x + 0.25f * p1.y;
+    he[r][1] = 0.25f * p1.x + 0.75f * p1.y;  ho[r][1] = 0.75f * p1.y + 0.25f * p2.x;
+  }
+  f32x4 r0, r1;
+  r0[0] = 0.25f * he[0][0] + 0.75f * he[1][0];  r0[1] = 0.25f * ho[0][0] + 0.75f * ho[1][0];
+  r0[2] = 0.25f * he[0][1] + 0.75f * he[1][1];  r0[3] = 0.25f * ho[0][1] + 0.75f * ho[1][1];
+  r1[0] = 0.75f * he[1][0] + 0.25f * he[2][0];  r1[1] = 0.75f * ho[1][0] + 0.25f * ho[2][0];
+  r1[2] = 0.75f * he[1][1] + 0.25f * he[2][1];  r1[3] = 0.75f * ho[1][1] + 0.25f * ho[2][1];
+  *reinterpret_cast<f32x4*>(out) = r0;
+  *reinterpret_cast<f32x4*>(out + Wo) = r1;
+}
+
+__global__ __launch_bounds__(256) void fir_up2_tiled_kernel(FirArgs p) {
+  using TT = FirTileUp;
+  __shared__ float sx[TT::IR * TT::RS];
+  __shared__ float sr[TT::IR * TT::RS];
+  const int H = p.H, W = p.W;
+  const int tiles_x = (W + TT::TI_W - 1) / TT::TI_W;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int bc = blockIdx.y;
+  const float* plane = p.src + (size_t)bc * H * W;
+  float a = 1.f, s = 0.f;
+  if (p.in_scale) { a = p.in_scale[bc]; s = p.in_shift[bc]; }
+  const int ix0 = tx * TT::TI_W, iy0 = ty * TT::TI_H;
+  const bool raw = p.out_raw != nullptr;
+  fir_stage_tile<TT, TT::TI_W>(p, plane, iy0 - 1, ix0, a, s, sx, sr, raw);
+  __syncthreads();
+  const int jxl = 2 * (threadIdx.x & 31), iyl = threadIdx.x >> 5;
+  const int jx = ix0 + jxl, iy = iy0 + iyl;
+  if (jx >= W || iy >= H) return;       // W even: the pixel pair is inside or outside as a whole
+  const int Wo = 2 * W;
+  const size_t off = (size_t)bc * 4 * H * W + (size_t)(2 * iy) * Wo + 2 * jx;
+  fir_up2_tile_emit(sx, iyl, jxl, p.out + off, Wo);
+  if (raw) fir_up2_tile_emit(sr, iyl, jxl, p.out_raw + off, Wo);
+}
+
+inline bool fir_use_tiled(int W) { return W % 4 == 0 && W >= 64; }
+
 // Generic upfirdn2d (reference op/upfirdn2d.py:162-203 semantics): zero-insert by `up`, pad/crop, correlate with the
 // flipped kernel, decimate by `down`.  grid = (ceil(Ho*Wo/256), BC).
 struct UpfirdnArgs {

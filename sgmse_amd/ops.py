@@ -68,16 +68,27 @@ def group_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, *, act
     return out
 
 
-def fir_resample(x: torch.Tensor, up: bool) -> torch.Tensor:
-    """upsample_2d / downsample_2d with k=(1,3,3,1), factor 2 (reference up_or_down_sampling.py:195-257)."""
+def fir_resample(x: torch.Tensor, up: bool, in_scale: Optional[torch.Tensor] = None, in_shift: Optional[torch.Tensor] = None,
+                 in_act: bool = False, return_raw: bool = False):
+    """upsample_2d / downsample_2d with k=(1,3,3,1), factor 2 (reference up_or_down_sampling.py:195-257).
+
+    As fused inside the network's residual blocks (layerspp.py:243-262): with ``in_scale``/``in_shift`` ([B, C], the
+    folded GroupNorm affine) the resampler consumes ``act(x * in_scale + in_shift)`` without materialising it, and with
+    ``return_raw`` it also returns the resampled ``x`` itself (the shortcut branch) from the same pass."""
     ctx = default_context(x.device)
     x = _f32(x, "x", ctx.device)
     B, Cc, H, W = x.shape
     shape = (B, Cc, 2 * H, 2 * W) if up else (B, Cc, H // 2, W // 2)
     out = torch.empty(shape, dtype=torch.float32, device=ctx.device)
+    raw = torch.empty(shape, dtype=torch.float32, device=ctx.device) if return_raw else None
+    sc = _f32(in_scale, "in_scale", ctx.device)
+    sh = _f32(in_shift, "in_shift", ctx.device)
+    if (sc is None) != (sh is None) or (sc is not None and (tuple(sc.shape) != (B, Cc) or tuple(sh.shape) != (B, Cc))):
+        raise ValueError("in_scale and in_shift must both be given, with shape [B, C]")
     ctx.use_current_stream()
-    ctx.check(ctx.lib.sgmse_op_fir(ctx.h, x.data_ptr(), out.data_ptr(), B * Cc, H, W, int(up)))
-    return out
+    ctx.check(ctx.lib.sgmse_op_fir(ctx.h, x.data_ptr(), out.data_ptr(), B * Cc, H, W, int(up), _lib.ptr(sc), _lib.ptr(sh),
+                                   int(bool(in_act)), _lib.ptr(raw)))
+    return (out, raw) if return_raw else out
 
 
 def upfirdn2d(x: torch.Tensor, kernel: torch.Tensor, up: int = 1, down: int = 1, pad: Tuple[int, int] = (0, 0)) -> torch.Tensor:

@@ -70,6 +70,21 @@ def check_fir(dev, B=2, C=3, H=12, W=20):
     assert rel_l2(ops.fir_resample(x.to(dev), True).cpu(), NO.fir_up2(x)) < 1e-6
 
 
+def check_fir_fused(dev, B=1, C=2, H=20, W=72):
+    """The resamplers as the residual blocks use them: fused GroupNorm-affine + SiLU producer and the raw second output
+    (LDS-tiled kernels when W % 4 == 0 and W >= 64, per-pixel kernels otherwise)."""
+    from sgmse_amd import ops
+    g = gen(H * 100 + W)
+    x, sc, sh = R(g, B, C, H, W), R(g, B, C), R(g, B, C)
+    xin = x * sc[:, :, None, None] + sh[:, :, None, None]
+    xin = xin * torch.sigmoid(xin)
+    for up in (False, True):
+        f = NO.fir_up2 if up else NO.fir_down2
+        out, raw = ops.fir_resample(x.to(dev), up, in_scale=sc.to(dev), in_shift=sh.to(dev), in_act=True, return_raw=True)
+        assert rel_l2(out.cpu(), f(xin)) < 2e-6 and rel_l2(raw.cpu(), f(x)) < 1e-6, (up, H, W)
+        assert rel_l2(ops.fir_resample(x.to(dev), up).cpu(), f(x)) < 1e-6
+
+
 def check_fir_golden(dev):
     """Against the reference's own upfirdn2d_native outputs (fixture fir.npz)."""
     from sgmse_amd import ops

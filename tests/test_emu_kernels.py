@@ -82,6 +82,10 @@ def test_groupnorm_concat_group_straddles_sources(emu):
 def test_fir(emu):
     P.check_fir(emu)
     P.check_fir(emu, 1, 2, 4, 1)
+    P.check_fir(emu, 1, 2, 20, 72)
+    P.check_fir_fused(emu)
+    P.check_fir_fused(emu, 2, 3, 6, 12)
+    P.check_fir_fused(emu, 1, 1, 16, 128)
     P.check_fir_golden(emu)
 
 

@@ -90,6 +90,10 @@ def test_fir(hip):
     P.check_fir(hip)
     P.check_fir(hip, 1, 2, 4, 1)
     P.check_fir(hip, 2, 128, 64, 128)
+    P.check_fir(hip, 1, 2, 20, 72)
+    P.check_fir_fused(hip)
+    P.check_fir_fused(hip, 2, 3, 6, 12)
+    P.check_fir_fused(hip, 2, 32, 256, 512)
     P.check_fir_golden(hip)
 
 
