@@ -13,8 +13,8 @@ namespace sgmse {
 // Measurement knob SGMSE_CONV_VARIANT (also the `variant` argument of sgmse_bench_conv):
 //   bit 0: operand prefetch off (compiler-ordered LDS reads)   bit 1: element-wise instead of float4 input staging
 //   bit 2: toggle the software-pipelined kernel (kernels_conv_pipe.h) for the 128 x 256 tiles
-//   bit 3: 1x1 convolutions through the LDS-tiled kernels instead of the streaming kernel (kernels_conv1x1.h)
-//   bit 4: 64-channel chunks in the streaming 1x1 kernel
+//   bit 3: 1x1 convolutions with 128-channel output blocks through the streaming kernel (kernels_conv1x1.h; measured
+//          slower than the LDS-tiled kernel, kept selectable for the record)   bit 4: its 64-channel-chunk shape
 inline int conv_variant() {
   static int v = [] { const char* e = getenv("SGMSE_CONV_VARIANT"); return e ? atoi(e) : 0; }();
   return v;
@@ -41,7 +41,7 @@ inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant)
 
 inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1) {
   const int v = variant < 0 ? conv_variant() : variant;
-  if (ks == 1 && pl.co_t == 128 && !(v & 8)) {
+  if (ks == 1 && pl.co_t == 128 && (v & 8)) {
     // streaming kernel chunk: 32 channels, or 64 with bit 4 (one wave = 128 co x 32 px of one row; an 8-row-per-workgroup
     // shape with two pixel fragments per wave needs > 256 registers and spills)
     const int kc = (v & 16) ? 64 : 32;

@@ -1,15 +1,17 @@
 // 1x1 convolution (NIN / residual-shortcut layers; reference layerspp.py:241-243 `conv1x1`, layers.py:568-581 `NIN`)
-// for 128-channel output blocks, as a streaming implicit GEMM.
+// for 128-channel output blocks, as a streaming implicit GEMM.  MEASURED SLOWER than the LDS-tiled kernel and therefore
+// not on the default path (SGMSE_CONV_VARIANT bit 3 selects it): 256->128 @ 8x256x512, 0.88 ms vs 0.79 ms plain,
+// 1.02 vs 0.89 ms with the fused producer + residual (profiles/r01_conv1x1_streaming.txt).
 //
-// A 1x1 convolution has no spatial reuse: with Cout = 128 every input element is worth only 256 FLOPs, so the layer
-// sits at the HBM / MFMA balance point and what matters is bytes in flight, not LDS tiling.  Routed through the 3x3
-// kernel's LDS pipeline it kept only ~16 KB per workgroup in flight and reached a third of the HBM rate
-// (profiles/r01_conv_microbench_run8_pipelined.txt, ks=1 rows).  Here the B operand (pixels) never touches LDS: the
-// MFMA B-fragment layout [k = lane>>5][px = lane&31] is a coalesced 128-byte row segment per half-wave, so each lane
-// loads its own operand straight from global memory, one K-chunk (32 channels = 32 dwords per lane, 64 KB per CU)
-// ahead of the MFMAs; the fused GroupNorm-affine + SiLU producer is applied once per element in registers.  One wave
-// owns all 128 output channels of its 32 x FP pixels (FC = 4), so no element is fetched twice inside a workgroup.
-// Only the weights (A operand, shared by the four waves) are staged through LDS, double-buffered per chunk.
+// Idea: a 1x1 convolution has no spatial reuse, and with Cout = 128 every input element is worth only 256 FLOPs, so
+// the layer sits near the HBM / MFMA balance point.  Here the B operand (pixels) never touches LDS: the MFMA B-fragment
+// layout [k = lane>>5][px = lane&31] is a coalesced 128-byte row segment per half-wave, so each lane loads its own
+// operand straight from global memory one K-chunk ahead of the MFMAs, and the fused GroupNorm-affine + SiLU producer
+// is applied once per element in registers.  One wave owns all 128 output channels (FC = 4) of one 32-pixel row
+// segment; two segments per wave (the 8-row tile) need > 256 registers and spill.  Only the weights (A operand,
+// shared by the four waves) are staged through LDS, double-buffered per chunk.  Why it loses: with one pixel fragment
+// per wave every MFMA needs its own A read (4 LDS reads per 4 MFMAs vs 6 per 8), and the layer is MFMA-bound at this
+// shape (1.75 ms of MFMA time vs 1.37 ms of HBM time at B = 32), so bytes in flight were not the limiter.
 //
 // Same k order (channel pairs ascending) and the same v_mfma_f32_32x32x2_f32 chain as conv_mfma_kernel<1,...>, same
 // epilogue: results are bit-identical to the other tile shapes.

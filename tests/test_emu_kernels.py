@@ -54,8 +54,9 @@ def test_sampler_48k_variant_against_oracle(emu):
     P.check_sampler_oracle(emu, "ncsnpp_48k", N=1, snr=0.33, F_=192, T=64, B=1)
 
 
-def test_conv1x1_streaming_kernel(emu):
-    """Cout % 128 == 0 routes 1x1 convolutions to conv1x1_stream_kernel (8-row and 4-row tiles, ragged edges, concat)."""
+def test_conv1x1_wide_output(emu):
+    """1x1 convolutions with 128-channel output blocks: ragged edges, concat, fused producer (the streaming variant of
+    the same shapes runs under SGMSE_CONV_VARIANT=8 in test_conv_kernel_variants)."""
     P.check_conv(emu, 1, 64, 128, 9, 33, 1)
     P.check_conv(emu, 2, 96, 256, 5, 40, 1, xform=True)
     P.check_conv(emu, 1, 160, 128, 16, 20, 1, dual=64, xform=True)

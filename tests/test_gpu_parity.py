@@ -57,8 +57,9 @@ def test_conv_direct(hip, shape):
     P.check_conv(hip, *shape, direct=True)
 
 
-def test_conv1x1_streaming_kernel(hip):
-    """Cout % 128 == 0 routes 1x1 convolutions to conv1x1_stream_kernel (8-row and 4-row tiles, ragged edges, concat)."""
+def test_conv1x1_wide_output(hip):
+    """1x1 convolutions with 128-channel output blocks: ragged edges, concat, fused producer (the streaming variant of
+    the same shapes runs under SGMSE_CONV_VARIANT=8 in test_conv_kernel_variants)."""
     P.check_conv(hip, 1, 64, 128, 9, 33, 1)
     P.check_conv(hip, 2, 96, 256, 5, 40, 1, xform=True)
     P.check_conv(hip, 1, 160, 128, 16, 20, 1, dual=64, xform=True)

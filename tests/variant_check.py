@@ -16,4 +16,6 @@ for shp in [(1, 64, 128, 9, 33, 3), (1, 128, 128, 8, 32, 3), (2, 32, 128, 20, 40
 P.check_conv(dev, 2, 96, 128, 12, 36, 3, dual=64, xform=True)
 P.check_conv(dev, 2, 128, 128, 16, 32, 3, dual=64, xform=True)
 P.check_conv(dev, 1, 64, 128, 8, 32, 1, dual=32, xform=True)
+P.check_conv(dev, 2, 96, 256, 5, 40, 1, xform=True)
+P.check_conv(dev, 1, 160, 128, 16, 20, 1, dual=64, xform=True)
 print("VARIANT-OK")
