@@ -829,9 +829,12 @@ class Engine {
     if (!prof_) return;
     drt::event_record(&ev_b_, stream_);
     drt::event_sync(&ev_b_);
-    prof_ms_[cls] += drt::event_elapsed_ms(ev_a_, ev_b_);
+    const float ms = drt::event_elapsed_ms(ev_a_, ev_b_);
+    prof_ms_[cls] += ms;
     prof_flops_[cls] += work;
     prof_n_[cls] += launches;
+    if (prof_dump_ && prof_note_[0]) fprintf(stderr, "[sgmse-prof] %s %.4f ms %.1f Gwork/s\n", prof_note_, ms, work / ms * 1e-6);
+    prof_note_[0] = 0;
   }
   void tock() { if (prof_) { if (!ev_init_) { drt::event_create(&ev_a_); drt::event_create(&ev_b_); ev_init_ = true; } drt::event_record(&ev_a_, stream_); } }
 
@@ -911,6 +914,9 @@ class Engine {
       ConvPlan pl{co_t, rows_, true};
       ca.w = (co_t == w.co_t) ? w.packed : w.packed32;
       launch_conv_mfma(ca, w.ks, pl, stream_);
+      if (prof_ && prof_dump_)
+        snprintf(prof_note_, sizeof prof_note_, "conv%dx%d %d->%d @%dx%dx%d tile %dco x %drows%s%s", w.ks, w.ks, Cin, w.cout, B_, a.H, a.W,
+                 co_t, rows_, res ? " +res" : "", xf.scale ? " +gn" : "");
       tick(w.ks == 3 ? ((co_t == 128 && pl.rows == 8) ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else {
       ca.w = w.oihw;
@@ -1142,6 +1148,8 @@ class Engine {
   Arena arena_; char* arena_base_ = nullptr; size_t arena_cap_ = 0;
   bool dry_ = false;
   long tile_min_blocks_ = [] { const char* e = getenv("SGMSE_TILE_MIN_BLOCKS"); return e ? atol(e) : 512L; }();        // measurement knob (profiles/r01_tile_sweep.txt)
+  bool prof_dump_ = [] { const char* e = getenv("SGMSE_PROFILE_DUMP"); return e && e[0] == '1'; }();   // per-launch lines from profile_forward
+  char prof_note_[160] = {0};
   bool fir_scalar_ = [] { const char* e = getenv("SGMSE_FIR_SCALAR"); return e && e[0] == '1'; }();                     // measurement knob
   bool fuse_gn_stats_ = [] { const char* e = getenv("SGMSE_FUSE_GN_STATS"); return !(e && e[0] == '0'); }();   // measurement knob
   int B_ = 0, shape_B_ = 0, shape_F_ = 0, shape_T_ = 0;

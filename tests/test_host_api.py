@@ -264,3 +264,53 @@ def test_reference_package_name_alias(tmp_path):
             ) % (ROOT, os.path.join(ROOT, "sgmse_amd", "compat"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "ALIAS-OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_evaluation_metrics_match_reference_functions():
+    """f4: the NumPy metrics against outputs of the reference's own functions (fixture from oracle/make_golden_metrics.py)."""
+    from conftest import GOLDEN
+    from sgmse_amd.util import other as O
+    z = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    s, n, s_hat = z["s"], z["n"], z["s_hat"]
+    for got, want in zip(O.si_sdr_components(s_hat, s, n), (z["s_target"], z["e_noise"], z["e_art"])):
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(O.energy_ratios(s_hat, s, n), z["energy_ratios"], rtol=1e-12)
+    np.testing.assert_allclose(O.si_sdr(s, s_hat), z["si_sdr"], rtol=1e-12)
+    np.testing.assert_allclose(O.snr_dB(s, n), z["snr_dB"], rtol=1e-12)
+    np.testing.assert_allclose(O.hp_filter(s_hat), z["hp"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(O.hp_filter(s_hat, cut_off=120, order=6, sr=48000), z["hp_48k"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(O.mean_conf_int(z["vals"]), z["mean_conf_int"], rtol=1e-12)
+    np.testing.assert_allclose(O.mean_conf_int(z["vals"], 0.9), z["mean_conf_int_90"], rtol=1e-12)
+    np.testing.assert_allclose(O.mean_std(z["with_nan"]), z["mean_std"], rtol=1e-12)
+    m = O.Method("m", "/x", ["a"])
+    for v in z["vals"]:
+        m.append("a", v)
+    np.testing.assert_allclose(m.get_mean_ci("a"), z["mean_conf_int"], rtol=1e-12)
+    assert O.print_mean_std(z["with_nan"], 1) == "{:.1f} ± {:.1f}".format(*z["mean_std"])
+
+
+def test_calc_metrics_on_a_wav_directory(tmp_path):
+    """calc_metrics end to end: clean / noisy / enhanced wav directories (incl. the `<id>_<snr>dB.wav` naming rule and a
+    sub-directory) -> per-file SI-SDR/SIR/SAR, csv and summary files."""
+    from scipy.io import wavfile
+    from sgmse_amd import calc_metrics as CM
+    from sgmse_amd.util.other import energy_ratios
+    rng = np.random.default_rng(0)
+    dirs = {k: tmp_path / k for k in ("clean", "noisy", "enh")}
+    for d in dirs.values():
+        (d / "sub").mkdir(parents=True)
+    expect = {}
+    for name, clean_name in (("p1_5dB.wav", "p1.wav"), ("sub/p2.wav", "sub/p2.wav")):
+        x = (0.3 * rng.standard_normal(3000)).astype(np.float32)
+        n = (0.1 * rng.standard_normal(3000)).astype(np.float32)
+        xh = (x + 0.3 * n + 0.01 * rng.standard_normal(3000)).astype(np.float32)
+        wavfile.write(str(dirs["clean"] / clean_name), 16000, x)
+        wavfile.write(str(dirs["noisy"] / name), 16000, x + n)
+        wavfile.write(str(dirs["enh"] / name), 16000, xh)
+        expect[name] = energy_ratios(xh.astype(np.float64), x.astype(np.float64), (x + n).astype(np.float64) - x.astype(np.float64))
+    data = CM.main(["--clean_dir", str(dirs["clean"]), "--noisy_dir", str(dirs["noisy"]), "--enhanced_dir", str(dirs["enh"])])
+    assert sorted(data["filename"]) == sorted(expect)
+    for i, fn in enumerate(data["filename"]):
+        np.testing.assert_allclose((data["si_sdr"][i], data["si_sir"][i], data["si_sar"][i]), expect[fn], rtol=1e-9)
+    assert (dirs["enh"] / "_results.csv").read_text().splitlines()[0] == "filename,pesq,estoi,si_sdr,si_sir,si_sar"
+    assert "SI-SDR:" in (dirs["enh"] / "_avg_results.txt").read_text()
