@@ -261,6 +261,7 @@ class Engine {
   explicit Engine(int device, void* stream) : device_(device) {
     SG_CHECK(drt::set_device(device));
     stream_ = reinterpret_cast<drt::stream_t>(stream);
+    read_knobs();
   }
   ~Engine() {
     for (void* p : owned_) drt::free_dev(p);
@@ -272,7 +273,7 @@ class Engine {
   void set_stream(void* s) { stream_ = reinterpret_cast<drt::stream_t>(s); }  // a captured graph can be launched on any stream
 
   // ---- weights ----------------------------------------------------------------------------------------------
-  void set_config(const NetCfg& c) { cfg_ = c; layout_ = build_layout(c); weights_ready_ = false; invalidate_graph(); }
+  void set_config(const NetCfg& c) { cfg_ = c; layout_ = build_layout(c); weights_ready_ = false; invalidate_graph(); read_knobs(); }
   const NetCfg& config() const { return cfg_; }
 
   void load_weights(const char* const* names, const void* const* ptrs, const long long* numels, int n, int on_device) {
@@ -767,6 +768,7 @@ class Engine {
     check_launch();
     weights_ready_ = true;
     shape_B_ = 0;
+    temb_rows_ = 0;      // the time-embedding tables are sized by nf / the Dense layout of THIS net
   }
 
   // ---- shape-dependent buffers --------------------------------------------------------------------------------
@@ -1147,11 +1149,20 @@ class Engine {
 
   Arena arena_; char* arena_base_ = nullptr; size_t arena_cap_ = 0;
   bool dry_ = false;
-  long tile_min_blocks_ = [] { const char* e = getenv("SGMSE_TILE_MIN_BLOCKS"); return e ? atol(e) : 512L; }();        // measurement knob (profiles/r01_tile_sweep.txt)
-  bool prof_dump_ = [] { const char* e = getenv("SGMSE_PROFILE_DUMP"); return e && e[0] == '1'; }();   // per-launch lines from profile_forward
+  // measurement knobs, re-read from the environment at every configure (so one process can compare settings)
+  void read_knobs() {
+    auto flag = [](const char* name, bool dflt) { const char* e = getenv(name); return e ? e[0] == '1' : dflt; };
+    const char* e = getenv("SGMSE_TILE_MIN_BLOCKS");
+    tile_min_blocks_ = e ? atol(e) : 512L;               // profiles/r01_tile_sweep.txt
+    prof_dump_ = flag("SGMSE_PROFILE_DUMP", false);      // per-launch lines from profile_forward
+    fir_scalar_ = flag("SGMSE_FIR_SCALAR", false);       // per-pixel FIR kernels everywhere
+    fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
+  }
+  long tile_min_blocks_ = 512;
+  bool prof_dump_ = false;
   char prof_note_[160] = {0};
-  bool fir_scalar_ = [] { const char* e = getenv("SGMSE_FIR_SCALAR"); return e && e[0] == '1'; }();                     // measurement knob
-  bool fuse_gn_stats_ = [] { const char* e = getenv("SGMSE_FUSE_GN_STATS"); return !(e && e[0] == '0'); }();   // measurement knob
+  bool fir_scalar_ = false;
+  bool fuse_gn_stats_ = true;
   int B_ = 0, shape_B_ = 0, shape_F_ = 0, shape_T_ = 0;
   float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr, *sy_ = nullptr; size_t samp_n_ = 0;
   int* step_ctr_ = nullptr;

@@ -13,6 +13,14 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x16_bf16: D[32x32] += A[32x16] * B[16x32], operands = 8 bf16 per lane packed in 4 dwords
+// (lane l: row/col l & 31, k group l >> 5), fp32 accumulate; C/D layout as the 32x32x2 f32 form
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 #define DRT_LAUNCH(kern, grid, block, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)

@@ -58,6 +58,7 @@ struct WaveState {
   int arrived = 0;
   unsigned gen = 0;
   float a[2][64], b[2][64];
+  float a8[2][64][8], b8[2][64][8];   // bf16 MFMA operands (widened)
 };
 
 struct Worker {
@@ -207,6 +208,32 @@ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     acc = fmaf(ws.a[p][i], ws.b[p][j], acc);            // k = 0
     acc = fmaf(ws.a[p][32 + i], ws.b[p][32 + j], acc);  // k = 1
     c[r] = acc;
+  }
+  return c;
+}
+
+// bf16 operands: 8 per lane (lane l: row/col l & 31, k group l >> 5); products are exact in fp32, the 16-term sum is
+// formed in double and rounded once (the hardware's internal order is unspecified; tests are tolerance-based)
+f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  Worker* w = tw;
+  int t = w->cur, wave = t >> 6, lane = t & 63, p = w->parity[t];
+  w->parity[t] ^= 1;
+  WaveState& ws = w->waves[wave];
+  for (int e = 0; e < 4; ++e) {
+    uint32_t av = a[e], bv = b[e], u;
+    u = av << 16; memcpy(&ws.a8[p][lane][2 * e], &u, 4);
+    u = av & 0xffff0000u; memcpy(&ws.a8[p][lane][2 * e + 1], &u, 4);
+    u = bv << 16; memcpy(&ws.b8[p][lane][2 * e], &u, 4);
+    u = bv & 0xffff0000u; memcpy(&ws.b8[p][lane][2 * e + 1], &u, 4);
+  }
+  wave_barrier(w, wave);
+  int j = lane & 31, hi = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    double acc = c[r];
+    for (int g = 0; g < 2; ++g)
+      for (int e = 0; e < 8; ++e) acc += (double)ws.a8[p][32 * g + i][e] * (double)ws.b8[p][32 * g + j][e];
+    c[r] = (float)acc;
   }
   return c;
 }

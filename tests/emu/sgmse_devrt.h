@@ -25,6 +25,7 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 
 typedef float f32x16 __attribute__((vector_size(64)));
 typedef float f32x4 __attribute__((vector_size(16)));
+typedef uint32_t u32x4 __attribute__((vector_size(16)));
 
 #define __global__
 #define __device__
@@ -42,6 +43,7 @@ float shfl_xor(float v, int mask);
 float shfl_idx(float v, int src_lane);
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
 f32x4 mfma_16x16x4(float a, float b, f32x4 c);
+f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c);
 }  // namespace emu
 
 #define threadIdx (emu::t_threadIdx)
@@ -53,6 +55,7 @@ static inline void __syncthreads() { emu::sync_block(); }
 static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return emu::shfl_xor(v, mask); }
 static inline float __shfl(float v, int lane, int width = 64) { (void)width; return emu::shfl_idx(v, lane); }
 static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) { return emu::mfma_32x32x2(a, b, c); }
+static inline f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) { return emu::mfma_32x32x16_bf16(a, b, c); }
 static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) { return emu::mfma_16x16x4(a, b, c); }
 #define __builtin_amdgcn_iglp_opt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
