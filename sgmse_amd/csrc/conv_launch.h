@@ -3,7 +3,11 @@
 #include "kernels_conv.h"
 #include "kernels_conv_pipe.h"
 #include "kernels_conv1x1.h"
+#include "kernels_conv_b3.h"
 
+#ifndef SGMSE_CONV_B3_DEFAULT
+#define SGMSE_CONV_B3_DEFAULT 0
+#endif
 #ifndef SGMSE_CONV_PIPE_DEFAULT
 #define SGMSE_CONV_PIPE_DEFAULT 1
 #endif
@@ -69,6 +73,15 @@ inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt:
   SGMSE_CONV_CASE(1, 64, 4, 2, 1, 2)
   SGMSE_CONV_CASE(1, 32, 4, 1, 1, 1)
 #undef SGMSE_CONV_CASE
+}
+
+// bf16x3 3x3 convolution (kernels_conv_b3.h); a.w = weights packed by pack_weights_b3_kernel
+inline bool conv_b3_eligible(int ks, int C1, int C2, int Cout) {
+  return ks == 3 && Cout % 128 == 0 && (C1 + C2) % 16 == 0 && (C2 == 0 || C1 % 16 == 0) && (C1 + C2) <= 512;
+}
+inline void launch_conv_b3(const ConvArgs& a, drt::stream_t st) {
+  const int tiles = a.B * ((a.H + 7) / 8) * ((a.W + 31) / 32);
+  DRT_LAUNCH(conv3x3_b3_kernel, dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
 }
 
 inline void launch_conv_direct(const ConvArgs& a, int ks, drt::stream_t st) {

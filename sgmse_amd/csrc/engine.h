@@ -232,6 +232,7 @@ struct ConvW {            // one convolution's parameters on the device
   const float* packed = nullptr; // MFMA layout (null if the shape is not MFMA-eligible)
   const float* packed32 = nullptr; // second MFMA layout with 32-channel output tiles: 4x more workgroups for launches that
                                    // would otherwise leave most CUs idle (the 16x32 ... 4x8 levels of the U-Net)
+  const float* packed_b3 = nullptr; // bf16x3 fragment layout (kernels_conv_b3.h), 3x3 with cout % 128 == 0, cin % 16 == 0
   const float* bias = nullptr;
   int ks = 1, cin = 0, cout = 0, co_t = 0;
 };
@@ -489,7 +490,14 @@ class Engine {
     a.src1 = x; a.src2 = x2; a.C1 = Cin - C2; a.C2 = C2; a.bias = bias; a.res = res; a.out_scale = out_scale; a.out = out;
     a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
-    if (pl.mfma && !force_direct && (C2 == 0 || a.C1 % ((ks == 3) ? 8 : 32) == 0)) {
+    if (force_direct == 2) {          // the bf16x3 kernel
+      SG_REQUIRE(conv_b3_eligible(ks, a.C1, C2, Cout), "op_conv2d: shape is not eligible for the bf16x3 kernel");
+      const float* pk = pack_b3(w_oihw, Cin, Cout, false);
+      a.w = pk;
+      launch_conv_b3(a, stream_);
+      SG_CHECK(drt::stream_sync(stream_));
+      free_tmp(const_cast<float*>(pk));
+    } else if (pl.mfma && !force_direct && (C2 == 0 || a.C1 % ((ks == 3) ? 8 : 32) == 0)) {
       const size_t ne = packed_weight_elems(ks, Cin, Cout, pl.co_t);
       float* pk = static_cast<float*>(dev_alloc_tmp(ne * 4));
       PackArgs pa{}; pa.src[0] = w_oihw; pa.nsrc = 1; pa.cout_per_src = Cout; pa.io = 0; pa.cin = Cin; pa.taps = ks * ks;
@@ -581,6 +589,8 @@ class Engine {
     if (variant >= 0 && (variant & 512)) { pl.rows = 4; variant &= ~512; }   // measurement knob: 128 co x 128 px tile
     int ablate = 0;
     if (variant >= 0) { ablate = (variant >> 12) & 15; variant &= 4095; }       // measurement knob: ablation bits 12..15
+    const bool b3 = variant >= 0 && (variant & 64);
+    SG_REQUIRE(!b3 || conv_b3_eligible(ks, Cin, 0, Cout), "bench_conv: shape is not eligible for the bf16x3 kernel");
     const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * Cout * H * W, nw = (size_t)Cout * Cin * ks * ks;
     const size_t ne = packed_weight_elems(ks, Cin, Cout, pl.co_t);
     float* x = static_cast<float*>(dev_alloc_tmp(nx * 4));
@@ -602,15 +612,19 @@ class Engine {
     if (fused) { a.in_scale = sc; a.in_shift = sc + (size_t)B * Cin; a.in_act = 1; a.res = r; a.bias = w; a.out_scale = 0.70710678f; }
     drt::event_t e0{}, e1{};
     drt::event_create(&e0); drt::event_create(&e1);
-    for (int i = 0; i < 2; ++i) launch_conv_mfma(a, ks, pl, stream_, variant);
+    const float* pk3 = nullptr;
+    if (b3) { pk3 = pack_b3(w, Cin, Cout, false); a.w = pk3; }
+    auto go = [&]() { if (b3) launch_conv_b3(a, stream_); else launch_conv_mfma(a, ks, pl, stream_, variant); };
+    for (int i = 0; i < 2; ++i) go();
     drt::event_record(&e0, stream_);
-    for (int i = 0; i < iters; ++i) launch_conv_mfma(a, ks, pl, stream_, variant);
+    for (int i = 0; i < iters; ++i) go();
     drt::event_record(&e1, stream_);
     drt::event_sync(&e1);
     const float ms = drt::event_elapsed_ms(e0, e1) / (float)iters;
     check_launch();
     drt::event_destroy(&e0); drt::event_destroy(&e1);
     for (float* q : {x, o, r, w, pk, sc}) free_tmp(q);
+    if (pk3) free_tmp(const_cast<float*>(pk3));
     return ms;
   }
 
@@ -699,7 +713,16 @@ class Engine {
         c.packed32 = pk32;
       }
     }
+    if (conv_b3_eligible(ks, cin, 0, cout)) c.packed_b3 = pack_b3(c.oihw, cin, cout, true);
     return c;
+  }
+
+  const float* pack_b3(const float* oihw, int cin, int cout, bool weight_owned) {
+    const size_t nu = packed_b3_u32(cin, cout);
+    uint32_t* pk = static_cast<uint32_t*>(weight_owned ? dev_alloc_w(nu * 4) : dev_alloc_tmp(nu * 4));
+    PackB3Args pa{oihw, pk, cin, cout, nu / 4};
+    DRT_LAUNCH(pack_weights_b3_kernel, dim3((unsigned)((pa.total + 255) / 256)), dim3(256), stream_, pa);
+    return reinterpret_cast<const float*>(pk);
   }
 
   // NIN weights W[cin][cout] (layers.py:549); nsrc of them concatenated along cout (fused q|k|v projection)
@@ -898,6 +921,10 @@ class Engine {
           if (nblk >= tile_min_blocks_) done = true;
         }
     }
+    // fp32-accurate bf16x3 kernel for the wide levels.  Decided per layer and per IMAGE (never by the batch size), because
+    // its results differ from the fp32-MFMA kernels in the last bits and an utterance must not depend on its batch.
+    const bool use_b3 = use_mfma && conv_b3_ && w.packed_b3 && conv_b3_eligible(w.ks, a.C, b ? b->C : 0, w.cout) &&
+                        (long)((a.H + 7) / 8) * ((a.W + 31) / 32) >= b3_min_tiles_;
     if (emit_stats && use_mfma && fuse_gn_stats_) {
       o.nsub = conv_plan_nsub(a.H, a.W);
       o.st = arena_.alloc((size_t)B_ * w.cout * o.nsub * 2);
@@ -912,7 +939,13 @@ class Engine {
     ca.res = res; ca.out_scale = out_scale; ca.out = o.p; ca.Cout = w.cout; ca.B = B_; ca.H = a.H; ca.W = a.W;
     tock();
     const double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
-    if (use_mfma) {
+    if (use_b3) {
+      ca.w = w.packed_b3;
+      launch_conv_b3(ca, stream_);
+      if (prof_ && prof_dump_)
+        snprintf(prof_note_, sizeof prof_note_, "conv3x3-b3 %d->%d @%dx%dx%d%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "");
+      tick(TC_CONV3_BIG, fl);
+    } else if (use_mfma) {
       ConvPlan pl{co_t, rows_, true};
       ca.w = (co_t == w.co_t) ? w.packed : w.packed32;
       launch_conv_mfma(ca, w.ks, pl, stream_);
@@ -1156,9 +1189,13 @@ class Engine {
     tile_min_blocks_ = e ? atol(e) : 512L;               // profiles/r01_tile_sweep.txt
     prof_dump_ = flag("SGMSE_PROFILE_DUMP", false);      // per-launch lines from profile_forward
     fir_scalar_ = flag("SGMSE_FIR_SCALAR", false);       // per-pixel FIR kernels everywhere
+    conv_b3_ = flag("SGMSE_CONV_B3", SGMSE_CONV_B3_DEFAULT != 0);   // bf16x3 3x3 kernel on the wide levels
+    e = getenv("SGMSE_B3_MIN_TILES");
+    b3_min_tiles_ = e ? atol(e) : 128L;                  // per-image 8x32 tiles from which a layer uses it
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
   }
-  long tile_min_blocks_ = 512;
+  long tile_min_blocks_ = 512, b3_min_tiles_ = 128;
+  bool conv_b3_ = false;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};
   bool fir_scalar_ = false;

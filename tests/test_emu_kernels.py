@@ -54,6 +54,12 @@ def test_sampler_48k_variant_against_oracle(emu):
     P.check_sampler_oracle(emu, "ncsnpp_48k", N=1, snr=0.33, F_=192, T=64, B=1)
 
 
+def test_conv3x3_bf16x3_kernel_has_fp32_accuracy(emu):
+    P.check_conv_b3(emu, 1, 32, 128, 9, 33)
+    P.check_conv_b3(emu, 2, 48, 128, 8, 32, xform=True)
+    P.check_conv_b3(emu, 1, 64, 256, 5, 40, dual=32, xform=True)
+
+
 def test_conv1x1_wide_output(emu):
     """1x1 convolutions with 128-channel output blocks: ragged edges, concat, fused producer (the streaming variant of
     the same shapes runs under SGMSE_CONV_VARIANT=8 in test_conv_kernel_variants)."""

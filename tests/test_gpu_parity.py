@@ -57,6 +57,15 @@ def test_conv_direct(hip, shape):
     P.check_conv(hip, *shape, direct=True)
 
 
+def test_conv3x3_bf16x3_kernel_has_fp32_accuracy(hip):
+    P.check_conv_b3(hip, 1, 32, 128, 9, 33)
+    P.check_conv_b3(hip, 2, 48, 128, 8, 32, xform=True)
+    P.check_conv_b3(hip, 1, 64, 256, 5, 40, dual=32, xform=True)
+    P.check_conv_b3(hip, 2, 128, 128, 64, 96)
+    P.check_conv_b3(hip, 1, 384, 128, 32, 64, dual=128, xform=True)
+    P.check_conv_b3(hip, 1, 512, 256, 16, 32, dual=256, xform=True)
+
+
 def test_conv1x1_wide_output(hip):
     """1x1 convolutions with 128-channel output blocks: ragged edges, concat, fused producer (the streaming variant of
     the same shapes runs under SGMSE_CONV_VARIANT=8 in test_conv_kernel_variants)."""
