@@ -6,7 +6,7 @@
 #include "kernels_conv_b3.h"
 
 #ifndef SGMSE_CONV_B3_DEFAULT
-#define SGMSE_CONV_B3_DEFAULT 0
+#define SGMSE_CONV_B3_DEFAULT 1
 #endif
 #ifndef SGMSE_CONV_PIPE_DEFAULT
 #define SGMSE_CONV_PIPE_DEFAULT 1

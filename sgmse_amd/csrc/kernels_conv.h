@@ -57,7 +57,8 @@ struct ConvArgs {
 // SiLU x*sigmoid(x) (nn.SiLU, reference layers.py:38-39) on the hardware exp2/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each,
 // relative error of the result < 4e-7, far inside the 1e-5 per-op parity gate) -- the fused producers evaluate it for every
 // staged element, so a libm-accurate expf + IEEE divide (~25 VALU instructions) would dominate the staging phase.
-__device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+// (__frcp_rn is NOT that: it expands to the full div_scale / div_fmas / div_fixup sequence.)
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ float silu_precise_f(float v) { return v / (1.0f + expf(-v)); }   // time-embedding MLP (tiny)
 
 template <int KS, int WC, int FC, int FP, int VEC = 0>

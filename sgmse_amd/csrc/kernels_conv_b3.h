@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
     s_sc[c] = xform ? p.in_scale[b * Cin + c] : 1.f;
     s_sh[c] = xform ? p.in_shift[b * Cin + c] : 0.f;
   }
-  const bool act = xform && p.in_act;
+  const float actf = (xform && p.in_act) ? 1.f : 0.f;   // arithmetic blend below: a branch would split the MFMA loop body
   const size_t HW = (size_t)H * W;
 
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
@@ -129,13 +129,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
   }
 
   float rin[C::NIT][8];
-  auto load_stage = [&](int c0) {          // raw global loads of stage c0 into registers (in flight during the MFMAs)
+  auto load_item = [&](int i, int c0) {    // raw global loads of one staged item of stage c0 (consumed >= 3 taps later)
     const bool first = c0 < p.C1;
     const float* base = first ? p.src1 + ((size_t)b * p.C1 + c0) * HW : p.src2 + ((size_t)b * p.C2 + (c0 - p.C1)) * HW;
 #pragma unroll
-    for (int i = 0; i < C::NIT; ++i)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) rin[i][e] = base[(size_t)(8 * it_g[i] + e) * HW + it_goff[i]];
+    for (int e = 0; e < 8; ++e) rin[i][e] = base[(size_t)(8 * it_g[i] + e) * HW + it_goff[i]];
   };
   auto store_item = [&](int i, int c0, u32x4* sbuf) {   // producer + split + LDS write of one staged item
     uint32_t hi[8], mid[8], lo[8];
@@ -144,7 +142,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
     for (int e = 0; e < 8; ++e) {
       const int ch = c0 + 8 * it_g[i] + e;
       float t = rin[i][e] * s_sc[ch] + s_sh[ch];
-      t = act ? silu_f(t) : t;
+      const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+      t *= actf * (sig - 1.0f) + 1.0f;      // SiLU when actf = 1, identity when 0
       t = ok ? t : 0.f;                     // zero padding applies to the producer's OUTPUT
       b3_split(t, hi[e], mid[e], lo[e]);
     }
@@ -174,13 +173,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
   // B fragment base of this lane inside a stage buffer (u32x4 units): pixel (row j + dy, col l31 + dx), k-group kg
   const int b_lane = (l31 * 2 + kg) * 3;
 
+  // one tap of one stage: 8 pixel fragments x 6 split products.  The three B reads of fragment j+1 are issued before
+  // the MFMAs of fragment j (order pinned with sched_barrier: left alone, the compiler sinks every LDS read to just in
+  // front of its first use and waits lgkmcnt(0) three times per fragment).
   auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[3]) {
     const int dy = tap / 3, dx = tap - 3 * dy;
     const u32x4* sb = sbuf + b_lane + (dy * C::TCOLS + dx) * 6;
+    u32x4 bq[2][3];
+    bq[0][0] = sb[0]; bq[0][1] = sb[1]; bq[0][2] = sb[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const u32x4* q = sb + j * C::TCOLS * 6;
-      const u32x4 bh = q[0], bm = q[1], bl = q[2];
+      if (j + 1 < 8) {
+        const u32x4* q = sb + (j + 1) * C::TCOLS * 6;
+        bq[(j + 1) & 1][0] = q[0]; bq[(j + 1) & 1][1] = q[1]; bq[(j + 1) & 1][2] = q[2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 bh = bq[j & 1][0], bm = bq[j & 1][1], bl = bq[j & 1][2];
       f32x16 c = acc[0][j];
       c = mfma_32x32x16_bf16(a[2], bh, c);      // small terms first
       c = mfma_32x32x16_bf16(a[0], bl, c);
@@ -189,11 +197,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
       c = mfma_32x32x16_bf16(a[0], bm, c);
       c = mfma_32x32x16_bf16(a[0], bh, c);
       acc[0][j] = c;
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   // prologue: stage 0 -> s_in0
-  load_stage(0);
+#pragma unroll
+  for (int i = 0; i < C::NIT; ++i) load_item(i, 0);
   __syncthreads();          // s_sc / s_sh visible
 #pragma unroll
   for (int i = 0; i < C::NIT; ++i) store_item(i, 0, s_in0);
@@ -203,23 +213,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
   load_a(0, 0, a0);
 #pragma unroll 1
   for (int st = 0; st < nst; ++st) {
-    const bool more = st + 1 < nst;
+    // the stage after this one, clamped: the last stage re-stages itself into the buffer nobody reads again, which
+    // keeps the loop body free of branches
+    const int stn = st + 1 < nst ? st + 1 : st;
     const u32x4* cur = (st & 1) ? s_in1 : s_in0;
     u32x4* nxt = (st & 1) ? s_in0 : s_in1;
-    if (more) load_stage((st + 1) * C::KC);
-    // taps, A fragments prefetched one tap ahead (alternating register sets); the next stage's producer + LDS writes
-    // are spread over the taps
+    // Per tap: the A fragments of the next tap first (vmcnt retires in order: they must be OLDER than the raw HBM loads
+    // of the next stage issued behind them, or every tap would wait for HBM), then one item of raw loads (taps 0-2);
+    // producer + split + LDS write of those items three or more taps later (taps 4, 6, 8).
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ntap = tap + 1 < 9 ? tap + 1 : 0;
-      const int nstg = tap + 1 < 9 ? st : (more ? st + 1 : st);
-      if (tap & 1) { load_a(nstg, ntap, a0); compute_tap(cur, tap, a1); }
-      else { load_a(nstg, ntap, a1); compute_tap(cur, tap, a0); }
-      if (more && tap % 3 == 2 && tap / 3 < C::NIT) store_item(tap / 3, (st + 1) * C::KC, nxt);
+      const int nstg = tap + 1 < 9 ? st : stn;
+      if (tap & 1) load_a(nstg, ntap, a0); else load_a(nstg, ntap, a1);
+      if (tap < C::NIT) load_item(tap, stn * C::KC);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap & 1) compute_tap(cur, tap, a1); else compute_tap(cur, tap, a0);
+      if (tap >= 4 && (tap & 1) == 0) store_item((tap - 4) / 2, stn * C::KC, nxt);
     }
-    // 9 taps: the last prefetch landed in a0 (tap 8 is even -> loaded a1? see below)
     __syncthreads();
-    // after an odd number of taps the register sets have swapped roles: tap 8 computed from a0 and prefetched into a1
+    // nine taps: the register sets have swapped roles (tap 8 computed from a0 and prefetched the next stage into a1)
 #pragma unroll
     for (int s = 0; s < 3; ++s) a0[s] = a1[s];
   }

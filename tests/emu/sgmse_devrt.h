@@ -64,6 +64,7 @@ static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __expf(x) expf(x)
 static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float atomicAdd(float* p, float v) {
   uint32_t* ip = reinterpret_cast<uint32_t*>(p);

@@ -194,6 +194,20 @@ def check_tile_independence(dev, name, batch=None):
     assert rel_l2(outs[0], torch.from_numpy(z["out"])[:len(x)]) < NET_TOL
 
 
+def check_forward_b3_everywhere(dev, name="fwd_nf128"):
+    """Network-level parity with the bf16x3 kernel on EVERY eligible 3x3 layer (SGMSE_B3_MIN_TILES=1; by default only the
+    wide levels use it), against the reference's own output, at the same gate as the fp32 kernels."""
+    old = os.environ.get("SGMSE_B3_MIN_TILES")
+    os.environ["SGMSE_B3_MIN_TILES"] = "1"
+    try:
+        check_forward_golden(dev, name)
+    finally:
+        if old is None:
+            os.environ.pop("SGMSE_B3_MIN_TILES", None)
+        else:
+            os.environ["SGMSE_B3_MIN_TILES"] = old
+
+
 def make_model(cfg, dev, P=None, sde="ouve", **kw):
     from sgmse_amd.model import ScoreModel
     P = synth.synth_params(cfg, seed=0) if P is None else P

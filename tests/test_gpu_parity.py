@@ -66,6 +66,10 @@ def test_conv3x3_bf16x3_kernel_has_fp32_accuracy(hip):
     P.check_conv_b3(hip, 1, 512, 256, 16, 32, dual=256, xform=True)
 
 
+def test_forward_with_bf16x3_on_every_eligible_layer(hip):
+    P.check_forward_b3_everywhere(hip)
+
+
 def test_conv1x1_wide_output(hip):
     """1x1 convolutions with 128-channel output blocks: ragged edges, concat, fused producer (the streaming variant of
     the same shapes runs under SGMSE_CONV_VARIANT=8 in test_conv_kernel_variants)."""

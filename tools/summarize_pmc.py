@@ -21,7 +21,7 @@ for d in sys.argv[1:]:
                 dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 out = {}
 for k, c in agg.items():
-    if "conv_mfma" not in k[0] and "gn_chan" not in k[0] and "fir_" not in k[0]:
+    if "conv" not in k[0] and "gn_chan" not in k[0] and "fir_" not in k[0]:
         continue
     m = {n: sum(v) / len(v) for n, v in c.items()}
     e = {"dispatches": len(dur[k]), "mean_duration_us_under_pmc": sum(dur[k]) / len(dur[k]) / 1e3, "counters_mean": m}
