@@ -1191,10 +1191,10 @@ class Engine {
     fir_scalar_ = flag("SGMSE_FIR_SCALAR", false);       // per-pixel FIR kernels everywhere
     conv_b3_ = flag("SGMSE_CONV_B3", SGMSE_CONV_B3_DEFAULT != 0);   // bf16x3 3x3 kernel on the wide levels
     e = getenv("SGMSE_B3_MIN_TILES");
-    b3_min_tiles_ = e ? atol(e) : 128L;                  // per-image 8x32 tiles from which a layer uses it
+    b3_min_tiles_ = e ? atol(e) : 32L;                   // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
   }
-  long tile_min_blocks_ = 512, b3_min_tiles_ = 128;
+  long tile_min_blocks_ = 512, b3_min_tiles_ = 32;
   bool conv_b3_ = false;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};

@@ -13,9 +13,9 @@
 // Layout (one workgroup = 128 co x 256 px = 8 rows x 32 columns, 4 waves, two workgroups per CU):
 //   * wave w owns the 32 output channels w of the block and all 8 pixel fragments (acc = 8 x 16 registers);
 //   * B operand (pixels): the input tile with halo (10 x 34 px) of a 16-channel K-stage lives in LDS already split,
-//     channels fastest: [row][col][k-group of 8 channels][split][8 bf16] = 96 B per pixel, so an MFMA B fragment of
-//     tap (dy,dx) is one ds_read_b128 per lane and the tap is an address offset.  Two stages (65 KB) are double
-//     buffered; the fused producer (GroupNorm affine + SiLU) and the split run once per staged element;
+//     channels fastest: [row][col][k-group of 8 channels][split][8 bf16] = 96 B per pixel (stride 112 B: bank
+//     conflicts), so an MFMA B fragment of tap (dy,dx) is one ds_read_b128 per lane and the tap is an address
+//     offset.  Two stages (76 KB) are double buffered; the fused producer (GroupNorm affine + SiLU) and the split run once per staged element;
 //   * A operand (weights): packed offline in fragment order [co block][stage][tap][split][wave][lane][8 bf16], so a
 //     fragment is one coalesced 16-byte global load per lane (L2-resident), prefetched one tap ahead.  No LDS.
 //   * K order: stage (16 channels) -> tap -> {6 split products}.  Same epilogue as the fp32 kernels (conv_epilogue).
@@ -26,8 +26,11 @@ namespace sgmse {
 
 struct ConvB3 {
   static constexpr int KC = 16, ROWS = 8, TROWS = 10, TCOLS = 34;
-  static constexpr int PX_U32 = 2 * 3 * 4;                     // dwords per staged pixel: 2 k-groups x 3 splits x 4
-  static constexpr int STAGE_U32 = TROWS * TCOLS * PX_U32;     // 8160 dwords = 32,640 B
+  // dwords per staged pixel: 2 k-groups x 3 splits x 4 = 24, padded to 28 -- with a 24-dword stride the 16 lanes that a
+  // ds_read_b128 services per LDS cycle collide pairwise on the 64 banks (lanes n and n+8: 48 % of all LDS cycles were
+  // conflict cycles, profiles/r01_pmc_conv_b3.json); 28 n mod 64 is distinct for every lane of a group
+  static constexpr int PX_U32 = 28, PX_V = PX_U32 / 4;
+  static constexpr int STAGE_U32 = TROWS * TCOLS * PX_U32;     // 9520 dwords = 38,080 B
   static constexpr int NITEM = TROWS * TCOLS * 2;              // (pixel, k-group) staging items per stage
   static constexpr int NIT = (NITEM + 255) / 256;              // per thread (3)
 };
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
     const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
     okmask |= (ok ? 1u : 0u) << i;
     it_goff[i] = ok ? gy * W + gx : 0;
-    it_loff[i] = ((r * C::TCOLS + c) * 2 + g) * 3;      // in u32x4 units
+    it_loff[i] = (r * C::TCOLS + c) * C::PX_V + g * 3;  // in u32x4 units
     it_g[i] = g;
   }
 
@@ -171,20 +174,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
     a[0] = q[0]; a[1] = q[4 * 64]; a[2] = q[2 * 4 * 64];
   };
   // B fragment base of this lane inside a stage buffer (u32x4 units): pixel (row j + dy, col l31 + dx), k-group kg
-  const int b_lane = (l31 * 2 + kg) * 3;
+  const int b_lane = l31 * C::PX_V + kg * 3;
 
   // one tap of one stage: 8 pixel fragments x 6 split products.  The three B reads of fragment j+1 are issued before
   // the MFMAs of fragment j (order pinned with sched_barrier: left alone, the compiler sinks every LDS read to just in
   // front of its first use and waits lgkmcnt(0) three times per fragment).
   auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[3]) {
     const int dy = tap / 3, dx = tap - 3 * dy;
-    const u32x4* sb = sbuf + b_lane + (dy * C::TCOLS + dx) * 6;
+    const u32x4* sb = sbuf + b_lane + (dy * C::TCOLS + dx) * C::PX_V;
     u32x4 bq[2][3];
     bq[0][0] = sb[0]; bq[0][1] = sb[1]; bq[0][2] = sb[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j + 1 < 8) {
-        const u32x4* q = sb + (j + 1) * C::TCOLS * 6;
+        const u32x4* q = sb + (j + 1) * C::TCOLS * C::PX_V;
         bq[(j + 1) & 1][0] = q[0]; bq[(j + 1) & 1][1] = q[1]; bq[(j + 1) & 1][2] = q[2];
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -229,6 +232,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
       if (tap < C::NIT) load_item(tap, stn * C::KC);
       __builtin_amdgcn_sched_barrier(0);
       if (tap & 1) compute_tap(cur, tap, a1); else compute_tap(cur, tap, a0);
+      // (slicing this producer work between the MFMAs with sched_group_barrier was tried: the compiler pairs the
+      // elements into packed-f32 ops, clusters them behind the MFMAs anyway and spills)
       if (tap >= 4 && (tap & 1) == 0) store_item((tap - 4) / 2, stn * C::KC, nxt);
     }
     __syncthreads();
