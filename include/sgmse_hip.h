@@ -128,7 +128,7 @@ int sgmse_upfirdn2d(sgmse_ctx* ctx, const float* input, const float* kernel, flo
  * conv2d: F.conv2d(cat[x, x2], w, bias, padding=ks/2) (layers.py:100-124), optionally with a fused per-(b,c)
  * affine(+SiLU) on the input, a fused residual and output scale: out = (conv + bias + res) * out_scale.
  * x holds Cin-C2 channels, x2 (may be NULL) the remaining C2.  force_direct = 1 selects the VALU kernel,
- * 2 the bf16x3 MFMA kernel (3x3, Cout % 128 == 0, channel counts % 16 == 0; error otherwise). */
+ * 2 / 3 the bf16x3 / fp16x2 split MFMA kernels (3x3, Cout % 128 == 0, channel counts % 16 == 0; error otherwise). */
 int sgmse_op_conv2d(sgmse_ctx* ctx, const float* x, const float* w_oihw, const float* bias, const float* res, float* out,
                     int B, int Cin, int Cout, int H, int W, int ks, float out_scale, int force_direct,
                     const float* in_scale, const float* in_shift, int in_act, const float* x2, int C2);

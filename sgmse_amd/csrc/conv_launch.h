@@ -5,8 +5,8 @@
 #include "kernels_conv1x1.h"
 #include "kernels_conv_b3.h"
 
-#ifndef SGMSE_CONV_B3_DEFAULT
-#define SGMSE_CONV_B3_DEFAULT 1
+#ifndef SGMSE_CONV_SPLIT_DEFAULT
+#define SGMSE_CONV_SPLIT_DEFAULT 1     // 0: fp32 MFMA everywhere, 1: bf16x3 on the wide levels, 2: fp16x2 on the wide levels
 #endif
 #ifndef SGMSE_CONV_PIPE_DEFAULT
 #define SGMSE_CONV_PIPE_DEFAULT 1
@@ -19,6 +19,7 @@ namespace sgmse {
 //   bit 2: toggle the software-pipelined kernel (kernels_conv_pipe.h) for the 128 x 256 tiles
 //   bit 3: 1x1 convolutions with 128-channel output blocks through the streaming kernel (kernels_conv1x1.h; measured
 //          slower than the LDS-tiled kernel, kept selectable for the record)   bit 4: its 64-channel-chunk shape
+//   bit 6 / bit 7: (sgmse_bench_conv only) the bf16x3 / fp16x2 split 3x3 kernel regardless of the engine's per-layer rule
 inline int conv_variant() {
   static int v = [] { const char* e = getenv("SGMSE_CONV_VARIANT"); return e ? atoi(e) : 0; }();
   return v;
@@ -79,9 +80,11 @@ inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt:
 inline bool conv_b3_eligible(int ks, int C1, int C2, int Cout) {
   return ks == 3 && Cout % 128 == 0 && (C1 + C2) % 16 == 0 && (C2 == 0 || C1 % 16 == 0) && (C1 + C2) <= 512;
 }
-inline void launch_conv_b3(const ConvArgs& a, drt::stream_t st) {
+// mode 1: bf16x3, mode 2: fp16x2 (a.acc_scale must point at the factor stored behind the packed weights)
+inline void launch_conv_split(const ConvArgs& a, int mode, drt::stream_t st) {
   const int tiles = a.B * ((a.H + 7) / 8) * ((a.W + 31) / 32);
-  DRT_LAUNCH(conv3x3_b3_kernel, dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
+  if (mode == 2) DRT_LAUNCH(conv3x3_split_kernel<SplitH2>, dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
+  else DRT_LAUNCH(conv3x3_split_kernel<SplitB3>, dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
 }
 
 inline void launch_conv_direct(const ConvArgs& a, int ks, drt::stream_t st) {

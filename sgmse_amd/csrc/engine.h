@@ -232,7 +232,9 @@ struct ConvW {            // one convolution's parameters on the device
   const float* packed = nullptr; // MFMA layout (null if the shape is not MFMA-eligible)
   const float* packed32 = nullptr; // second MFMA layout with 32-channel output tiles: 4x more workgroups for launches that
                                    // would otherwise leave most CUs idle (the 16x32 ... 4x8 levels of the U-Net)
-  const float* packed_b3 = nullptr; // bf16x3 fragment layout (kernels_conv_b3.h), 3x3 with cout % 128 == 0, cin % 16 == 0
+  const float* packed_split = nullptr; // split-kernel fragment layout (kernels_conv_b3.h) in the engine's split mode,
+                                       // 3x3 with cout % 128 == 0, cin % 16 == 0
+  const float* split_scale = nullptr;  // fp16x2: device scalar 2^-(k+4) behind the packed fragments
   const float* bias = nullptr;
   int ks = 1, cin = 0, cout = 0, co_t = 0;
 };
@@ -490,11 +492,11 @@ class Engine {
     a.src1 = x; a.src2 = x2; a.C1 = Cin - C2; a.C2 = C2; a.bias = bias; a.res = res; a.out_scale = out_scale; a.out = out;
     a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
-    if (force_direct == 2) {          // the bf16x3 kernel
-      SG_REQUIRE(conv_b3_eligible(ks, a.C1, C2, Cout), "op_conv2d: shape is not eligible for the bf16x3 kernel");
-      const float* pk = pack_b3(w_oihw, Cin, Cout, false);
+    if (force_direct == 2 || force_direct == 3) {          // the split kernels: 2 bf16x3, 3 fp16x2
+      SG_REQUIRE(conv_b3_eligible(ks, a.C1, C2, Cout), "op_conv2d: shape is not eligible for the split kernels");
+      const float* pk = pack_split(w_oihw, Cin, Cout, force_direct - 1, false, &a.acc_scale);
       a.w = pk;
-      launch_conv_b3(a, stream_);
+      launch_conv_split(a, force_direct - 1, stream_);
       SG_CHECK(drt::stream_sync(stream_));
       free_tmp(const_cast<float*>(pk));
     } else if (pl.mfma && !force_direct && (C2 == 0 || a.C1 % ((ks == 3) ? 8 : 32) == 0)) {
@@ -589,8 +591,9 @@ class Engine {
     if (variant >= 0 && (variant & 512)) { pl.rows = 4; variant &= ~512; }   // measurement knob: 128 co x 128 px tile
     int ablate = 0;
     if (variant >= 0) { ablate = (variant >> 12) & 15; variant &= 4095; }       // measurement knob: ablation bits 12..15
-    const bool b3 = variant >= 0 && (variant & 64);
-    SG_REQUIRE(!b3 || conv_b3_eligible(ks, Cin, 0, Cout), "bench_conv: shape is not eligible for the bf16x3 kernel");
+    const int smode = variant < 0 ? 0 : ((variant & 128) ? 2 : ((variant & 64) ? 1 : 0));
+    const bool b3 = smode != 0;
+    SG_REQUIRE(!b3 || conv_b3_eligible(ks, Cin, 0, Cout), "bench_conv: shape is not eligible for the split kernels");
     const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * Cout * H * W, nw = (size_t)Cout * Cin * ks * ks;
     const size_t ne = packed_weight_elems(ks, Cin, Cout, pl.co_t);
     float* x = static_cast<float*>(dev_alloc_tmp(nx * 4));
@@ -613,8 +616,8 @@ class Engine {
     drt::event_t e0{}, e1{};
     drt::event_create(&e0); drt::event_create(&e1);
     const float* pk3 = nullptr;
-    if (b3) { pk3 = pack_b3(w, Cin, Cout, false); a.w = pk3; }
-    auto go = [&]() { if (b3) launch_conv_b3(a, stream_); else launch_conv_mfma(a, ks, pl, stream_, variant); };
+    if (b3) { pk3 = pack_split(w, Cin, Cout, smode, false, &a.acc_scale); a.w = pk3; }
+    auto go = [&]() { if (b3) launch_conv_split(a, smode, stream_); else launch_conv_mfma(a, ks, pl, stream_, variant); };
     for (int i = 0; i < 2; ++i) go();
     drt::event_record(&e0, stream_);
     for (int i = 0; i < iters; ++i) go();
@@ -713,15 +716,29 @@ class Engine {
         c.packed32 = pk32;
       }
     }
-    if (conv_b3_eligible(ks, cin, 0, cout)) c.packed_b3 = pack_b3(c.oihw, cin, cout, true);
+    if (split_mode_ && conv_b3_eligible(ks, cin, 0, cout)) c.packed_split = pack_split(c.oihw, cin, cout, split_mode_, true, &c.split_scale);
     return c;
   }
 
-  const float* pack_b3(const float* oihw, int cin, int cout, bool weight_owned) {
-    const size_t nu = packed_b3_u32(cin, cout);
-    uint32_t* pk = static_cast<uint32_t*>(weight_owned ? dev_alloc_w(nu * 4) : dev_alloc_tmp(nu * 4));
-    PackB3Args pa{oihw, pk, cin, cout, nu / 4};
-    DRT_LAUNCH(pack_weights_b3_kernel, dim3((unsigned)((pa.total + 255) / 256)), dim3(256), stream_, pa);
+  // weights in the fragment order of conv3x3_split_kernel (mode 1: bf16x3, 2: fp16x2 with the layer's power-of-two scale)
+  const float* pack_split(const float* oihw, int cin, int cout, int mode, bool weight_owned, const float** scale_out) {
+    const size_t frags = mode == 2 ? packed_split_frags<SplitH2>(cin, cout) : packed_split_frags<SplitB3>(cin, cout);
+    const size_t bytes = frags * 16 + 16;
+    uint32_t* pk = static_cast<uint32_t*>(weight_owned ? dev_alloc_w(bytes) : dev_alloc_tmp(bytes));
+    PackSplitArgs pa{oihw, pk, cin, cout, frags, nullptr};
+    const dim3 grid((unsigned)((frags + 255) / 256));
+    if (mode == 2) {
+      float* amax = reinterpret_cast<float*>(pk) + frags * 4 + 1;     // scratch word behind the scale
+      SG_CHECK(drt::memset_dev(amax, 0, 4, stream_));
+      const size_t n = (size_t)cout * cin * 9;
+      DRT_LAUNCH(absmax_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), stream_, oihw, n, amax);
+      pa.absmax = amax;
+      DRT_LAUNCH(pack_weights_split_kernel<SplitH2>, grid, dim3(256), stream_, pa);
+      *scale_out = reinterpret_cast<const float*>(pk) + frags * 4;
+    } else {
+      DRT_LAUNCH(pack_weights_split_kernel<SplitB3>, grid, dim3(256), stream_, pa);
+      *scale_out = nullptr;
+    }
     return reinterpret_cast<const float*>(pk);
   }
 
@@ -923,8 +940,9 @@ class Engine {
     }
     // fp32-accurate bf16x3 kernel for the wide levels.  Decided per layer and per IMAGE (never by the batch size), because
     // its results differ from the fp32-MFMA kernels in the last bits and an utterance must not depend on its batch.
-    const bool use_b3 = use_mfma && conv_b3_ && w.packed_b3 && conv_b3_eligible(w.ks, a.C, b ? b->C : 0, w.cout) &&
-                        (long)((a.H + 7) / 8) * ((a.W + 31) / 32) >= b3_min_tiles_;
+    const bool use_b3 = use_mfma && w.packed_split && conv_b3_eligible(w.ks, a.C, b ? b->C : 0, w.cout) &&
+                        (long)((a.H + 7) / 8) * ((a.W + 31) / 32) >= b3_min_tiles_ &&
+                        (split_mode_ != 2 || xf.scale != nullptr);   // fp16x2 presumes the O(1) output of a GroupNorm producer
     if (emit_stats && use_mfma && fuse_gn_stats_) {
       o.nsub = conv_plan_nsub(a.H, a.W);
       o.st = arena_.alloc((size_t)B_ * w.cout * o.nsub * 2);
@@ -940,10 +958,10 @@ class Engine {
     tock();
     const double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
     if (use_b3) {
-      ca.w = w.packed_b3;
-      launch_conv_b3(ca, stream_);
+      ca.w = w.packed_split; ca.acc_scale = w.split_scale;
+      launch_conv_split(ca, split_mode_, stream_);
       if (prof_ && prof_dump_)
-        snprintf(prof_note_, sizeof prof_note_, "conv3x3-b3 %d->%d @%dx%dx%d%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "");
+        snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "");
       tick(TC_CONV3_BIG, fl);
     } else if (use_mfma) {
       ConvPlan pl{co_t, rows_, true};
@@ -1189,13 +1207,15 @@ class Engine {
     tile_min_blocks_ = e ? atol(e) : 512L;               // profiles/r01_tile_sweep.txt
     prof_dump_ = flag("SGMSE_PROFILE_DUMP", false);      // per-launch lines from profile_forward
     fir_scalar_ = flag("SGMSE_FIR_SCALAR", false);       // per-pixel FIR kernels everywhere
-    conv_b3_ = flag("SGMSE_CONV_B3", SGMSE_CONV_B3_DEFAULT != 0);   // bf16x3 3x3 kernel on the wide levels
+    e = getenv("SGMSE_CONV_SPLIT");                      // 0: fp32 MFMA only, 1: bf16x3, 2: fp16x2 on the wide levels
+    split_mode_ = e ? atoi(e) : SGMSE_CONV_SPLIT_DEFAULT;
+    SG_REQUIRE(split_mode_ >= 0 && split_mode_ <= 2, "SGMSE_CONV_SPLIT must be 0, 1 or 2");
     e = getenv("SGMSE_B3_MIN_TILES");
     b3_min_tiles_ = e ? atol(e) : 32L;                   // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
   }
   long tile_min_blocks_ = 512, b3_min_tiles_ = 32;
-  bool conv_b3_ = false;
+  int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};
   bool fir_scalar_ = false;

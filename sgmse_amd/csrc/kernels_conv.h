@@ -40,7 +40,8 @@ struct ConvArgs {
   const float* in_scale; const float* in_shift;  // [B][C1+C2] fused GroupNorm affine, or null
   int in_act;              // 1: SiLU after the affine
   const float* res;        // residual [B][Cout][H][W] or null
-  float out_scale;         // out = (acc + bias + bias2 + res) * out_scale
+  const float* acc_scale;  // device scalar multiplying the accumulator first (split kernels with pre-scaled operands), or null
+  float out_scale;         // out = (acc * acc_scale + bias + bias2 + res) * out_scale
   float* out;
   int Cout, B, H, W;
   // optional GroupNorm statistics of the stored output, fused into the epilogue: per (b, co, sub-tile) partial
@@ -93,6 +94,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
   const int H = p.H, W = p.W;
   const int x0 = tx * 32, y0 = ty * ROWS;
   const int x = x0 + l31;
+  const float as = p.acc_scale ? *p.acc_scale : 1.0f;     // exact power of two (or 1)
   const float* b2 = nullptr;
   if (p.bias2) {
     const int step = p.step_ptr ? *p.step_ptr : 0;
@@ -141,7 +143,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co_base + (r & 3) + 8 * (r >> 2);
-        float v = (acc[i][j][r] + bv[r] + rr[j & 1][r]) * p.out_scale;
+        float v = (acc[i][j][r] * as + bv[r] + rr[j & 1][r]) * p.out_scale;
         const bool ok = pok && co < p.Cout;
         if (ok) {
           const size_t o = ((size_t)(b * p.Cout + co) * H + y) * W + x;

@@ -1,93 +1,156 @@
-// 3x3 convolution as an fp32-accurate implicit GEMM on the bf16 matrix pipe ("bf16x3": three-way operand split).
+// 3x3 convolution as an fp32-accurate implicit GEMM on the 16-bit matrix pipe: every fp32 operand is split into a few
+// 16-bit terms whose partial products (exact in fp32) are accumulated in fp32 by v_mfma_f32_32x32x16_{bf16,f16}.
 //
-// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate, and the fp32 3x3 kernel (kernels_conv_pipe.h) already
-// sits at ~81 % of that fp32 peak.  Here every fp32 operand x is split EXACTLY into three bf16 terms
-//     x = hi + mid + lo,   hi = x & 0xffff0000,  mid = (x - hi) & 0xffff0000,  lo = x - hi - mid   (8 + 8 + 8 mantissa bits)
-// and a product a*b is accumulated in fp32 from the six bf16 x bf16 partial products whose weight is >= 2^-16
-//     hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi
-// (each exact in fp32).  The dropped terms (mid*lo, lo*mid, lo*lo) are below 2^-23 relative to a*b -- the size of one
-// fp32 rounding -- so the result has fp32 accuracy (tests: same 1e-5 per-op / 2e-5 per-network gates as the fp32
-// kernels, and a direct comparison against an fp64 convolution).  Six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles for
-// K = 16) replace eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles): 2.67x the fp32 MFMA peak.
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the 16-bit MFMA rate, and the fp32 3x3 kernel (kernels_conv_pipe.h) already
+// sits at ~81 % of that fp32 peak.  Two split policies:
+//
+//   SplitB3 ("bf16x3"): x = hi + mid + lo EXACTLY, hi = x & 0xffff0000, mid = (x - hi) & 0xffff0000, lo = x - hi - mid
+//     (8 + 8 + 8 mantissa bits, truncating).  a*b is accumulated from the six partial products of weight >= 2^-16:
+//     hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi; the dropped terms are < 2^-23 relative to a*b, the size of one
+//     fp32 rounding.  Six MFMAs of K = 16 (6 x 32 cycles) replace eight fp32 MFMAs of K = 2 (8 x 64): 2.67x the fp32 peak.
+//
+//   SplitH2 ("fp16x2"): x * 2^s = hi + lo + e, hi = RN_f16(x 2^s), lo = RN_f16(x 2^s - hi), |e| <= 2^-24 |x 2^s| (two
+//     round-to-nearest 11-bit terms cover 22-23 bits plus the sign of lo).  a*b from hi*hi + hi*lo + lo*hi (lo*lo <=
+//     2^-24): relative error <= ~3 x 2^-24 per product, i.e. within one bit of fp32.  Three MFMAs: 5.3x the fp32 peak.
+//     fp16 has a narrow exponent range, so both operands are pre-scaled by exact powers of two: activations (always the
+//     output of the fused GroupNorm+SiLU producer here: O(1)) by 2^4 and saturated at +-65504 (|x| > 4094 cannot come
+//     out of a GroupNorm), the weights of a layer by 2^k with max|w| 2^k in [2^13, 2^14) (chosen by the packing kernel,
+//     which also stores 2^-(k+4) for the epilogue).  Small operands fall into fp16 subnormals; their ABSOLUTE error
+//     stays <= 2^-25 of the scaled unit, which is what matters for a sum.
+//
+// Both are checked against an fp64 convolution next to the fp32-MFMA kernel (tests: check_conv_split) and pass the same
+// 1e-5 per-op / 2e-5 per-network parity gates as the fp32 kernels.
 //
 // Layout (one workgroup = 128 co x 256 px = 8 rows x 32 columns, 4 waves, two workgroups per CU):
 //   * wave w owns the 32 output channels w of the block and all 8 pixel fragments (acc = 8 x 16 registers);
 //   * B operand (pixels): the input tile with halo (10 x 34 px) of a 16-channel K-stage lives in LDS already split,
-//     channels fastest: [row][col][k-group of 8 channels][split][8 bf16] = 96 B per pixel (stride 112 B: bank
-//     conflicts), so an MFMA B fragment of tap (dy,dx) is one ds_read_b128 per lane and the tap is an address
-//     offset.  Two stages (76 KB) are double buffered; the fused producer (GroupNorm affine + SiLU) and the split run once per staged element;
-//   * A operand (weights): packed offline in fragment order [co block][stage][tap][split][wave][lane][8 bf16], so a
+//     channels fastest: [row][col][k-group of 8 channels][split][8 x 16 bit], so an MFMA B fragment of tap (dy,dx) is
+//     one ds_read_b128 per lane and the tap is an address offset.  The pixel stride is padded (PX_V) so that the 16
+//     lanes a ds_read_b128 services per LDS cycle hit distinct banks.  Two stages are double buffered; the fused
+//     producer (GroupNorm affine + SiLU) and the split run once per staged element;
+//   * A operand (weights): packed offline in fragment order [co block][stage][tap][split][wave][lane][8 x 16 bit], so a
 //     fragment is one coalesced 16-byte global load per lane (L2-resident), prefetched one tap ahead.  No LDS.
-//   * K order: stage (16 channels) -> tap -> {6 split products}.  Same epilogue as the fp32 kernels (conv_epilogue).
+//   * K order: stage (16 channels) -> tap -> split products, small terms first.  Epilogue shared with the fp32 kernels.
 #pragma once
 #include "kernels_conv.h"
 
 namespace sgmse {
 
-struct ConvB3 {
+struct SplitB3 {
+  static constexpr int NS = 3;          // split terms per operand
+  static constexpr int NP = 6;          // partial products
+  static constexpr int PX_V = 7;        // u32x4 per staged pixel (2 k-groups x 3 splits = 6, padded: 28 n mod 64 distinct)
+  static constexpr bool SCALED = false;
+  __device__ static constexpr int pa(int k) { return k == 0 ? 2 : (k == 2 || k == 3) ? 1 : 0; }   // (a term, b term),
+  __device__ static constexpr int pb(int k) { return k == 1 ? 2 : (k == 2 || k == 4) ? 1 : 0; }   // small first
+  __device__ static __forceinline__ void split(float x, uint32_t (&t)[3]) {   // 16-bit patterns in the low halves
+    const uint32_t xb = __builtin_bit_cast(uint32_t, x);
+    const uint32_t hi = xb & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, hi);
+    const uint32_t mid = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, mid);
+    t[0] = hi >> 16; t[1] = mid >> 16; t[2] = __builtin_bit_cast(uint32_t, r2) >> 16;
+  }
+  __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) { return mfma_32x32x16_bf16(a, b, c); }
+};
+
+struct SplitH2 {
+  static constexpr int NS = 2;
+  static constexpr int NP = 3;
+  static constexpr int PX_V = 5;        // 2 k-groups x 2 splits = 4, padded: 20 n mod 64 distinct
+  static constexpr bool SCALED = true;
+  __device__ static constexpr int pa(int k) { return k == 0 ? 1 : 0; }
+  __device__ static constexpr int pb(int k) { return k == 1 ? 1 : 0; }
+  __device__ static __forceinline__ void split(float x, uint32_t (&t)[2]) {   // x already scaled and saturated
+    const uint32_t hi = drt_f32_to_f16(x);
+    const float r = x - drt_f16_to_f32(hi);
+    t[0] = hi; t[1] = drt_f32_to_f16(r);
+  }
+  __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) { return mfma_32x32x16_f16(a, b, c); }
+};
+constexpr float kH2XScale = 16.f;
+
+struct ConvSplitGeom {
   static constexpr int KC = 16, ROWS = 8, TROWS = 10, TCOLS = 34;
-  // dwords per staged pixel: 2 k-groups x 3 splits x 4 = 24, padded to 28 -- with a 24-dword stride the 16 lanes that a
-  // ds_read_b128 services per LDS cycle collide pairwise on the 64 banks (lanes n and n+8: 48 % of all LDS cycles were
-  // conflict cycles, profiles/r01_pmc_conv_b3.json); 28 n mod 64 is distinct for every lane of a group
-  static constexpr int PX_U32 = 28, PX_V = PX_U32 / 4;
-  static constexpr int STAGE_U32 = TROWS * TCOLS * PX_U32;     // 9520 dwords = 38,080 B
   static constexpr int NITEM = TROWS * TCOLS * 2;              // (pixel, k-group) staging items per stage
   static constexpr int NIT = (NITEM + 255) / 256;              // per thread (3)
 };
 
-// exact three-way bf16 split of an fp32 value (truncating; all three parts carry the sign of x)
-__device__ __forceinline__ void b3_split(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-  const uint32_t xb = __builtin_bit_cast(uint32_t, x);
-  hi = xb & 0xffff0000u;
-  const float r1 = x - __builtin_bit_cast(float, hi);
-  mid = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-  const float r2 = r1 - __builtin_bit_cast(float, mid);
-  lo = __builtin_bit_cast(uint32_t, r2) & 0xffff0000u;
+// Weight packing.  src: OIHW fp32 [Cout][Cin][3][3]; dst: u32x4 [nCoBlk][Cin/16][9][NS][4][64], followed (SplitH2) by
+// one float: the factor 2^-(k+4) that takes the accumulator back to the unscaled convolution.  `absmax` (device,
+// SplitH2 only) = max |w| of the layer, from absmax_kernel.  One thread per 16-byte fragment element.
+struct PackSplitArgs { const float* src; uint32_t* dst; int cin, cout; size_t total; const float* absmax; };
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t n, float* out) {   // *out zeroed by the caller
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) drt_atomic_max_nonneg(out, m);
 }
 
-// Weight packing for conv3x3_b3_kernel.  src: OIHW fp32 [Cout][Cin][3][3]; dst: u32x4 [nCoBlk][Cin/16][9][3][4][64].
-// One thread per (.., lane) 16-byte fragment element.
-struct PackB3Args { const float* src; uint32_t* dst; int cin, cout; size_t total; };
+// exact power of two 2^k with max|w| 2^k in [2^13, 2^14)
+__device__ __forceinline__ float h2_weight_scale(float absmax) {
+  if (!(absmax > 0.f)) return 1.f;
+  const int e = (int)((__builtin_bit_cast(uint32_t, absmax) >> 23) & 0xff) - 127;    // floor(log2(absmax)) for normals
+  int k = 13 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  return __builtin_bit_cast(float, (uint32_t)(k + 127) << 23);
+}
 
-__global__ __launch_bounds__(256) void pack_weights_b3_kernel(PackB3Args p) {
+template <class S>
+__global__ __launch_bounds__(256) void pack_weights_split_kernel(PackSplitArgs p) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= p.total) return;
+  float wscale = 1.f;
+  if (S::SCALED) {
+    wscale = h2_weight_scale(*p.absmax);
+    if (e == 0) reinterpret_cast<float*>(p.dst)[p.total * 4] = 1.f / (wscale * kH2XScale);
+  }
   const int lane = (int)(e & 63);
   size_t r = e >> 6;
   const int w = (int)(r & 3); r >>= 2;
-  const int split = (int)(r % 3); r /= 3;
+  const int split = (int)(r % S::NS); r /= S::NS;
   const int tap = (int)(r % 9); r /= 9;
   const int nst = p.cin / 16;
   const int st = (int)(r % nst);
   const int blk = (int)(r / nst);
   const int co = blk * 128 + w * 32 + (lane & 31);
   const int c0 = st * 16 + 8 * (lane >> 5);
-  uint32_t out[4];
+  u32x4 o;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     uint32_t part[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int c = c0 + 2 * q + h;
-      const float v = co < p.cout ? p.src[((size_t)co * p.cin + c) * 9 + tap] : 0.f;
-      uint32_t hi, mid, lo;
-      b3_split(v, hi, mid, lo);
-      part[h] = split == 0 ? hi : (split == 1 ? mid : lo);
+      const float v = (co < p.cout ? p.src[((size_t)co * p.cin + c) * 9 + tap] : 0.f) * wscale;
+      uint32_t t[S::NS];
+      S::split(v, t);
+      uint32_t sel = t[0];
+#pragma unroll
+      for (int s = 1; s < S::NS; ++s) sel = split == s ? t[s] : sel;
+      part[h] = sel;
     }
-    out[q] = (part[0] >> 16) | part[1];
+    o[q] = part[0] | (part[1] << 16);
   }
-  u32x4 o = {out[0], out[1], out[2], out[3]};
   reinterpret_cast<u32x4*>(p.dst)[e] = o;
 }
 
-inline size_t packed_b3_u32(int cin, int cout) { return (size_t)((cout + 127) / 128) * (cin / 16) * 9 * 3 * 4 * 64 * 4; }
+template <class S>
+inline size_t packed_split_frags(int cin, int cout) { return (size_t)((cout + 127) / 128) * (cin / 16) * 9 * S::NS * 4 * 64; }
+template <class S>
+inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<S>(cin, cout) * 16 + 16; }
 
-__global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
-  using C = ConvB3;
+template <class S>
+__global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
+  using C = ConvSplitGeom;
   using T = ConvTile<3, 4, 1, 8, 1>;       // epilogue geometry: 4 channel-waves x 1 fragment, 8 pixel fragments
   static_assert(T::CO_T == 128 && T::ROWS == 8, "tile");
-  __shared__ u32x4 s_in0[C::STAGE_U32 / 4];
-  __shared__ u32x4 s_in1[C::STAGE_U32 / 4];
+  constexpr int NS = S::NS, PX_V = S::PX_V;
+  constexpr int STAGE_V = C::TROWS * C::TCOLS * PX_V;
+  __shared__ u32x4 s_in0[STAGE_V];
+  __shared__ u32x4 s_in1[STAGE_V];
   __shared__ float s_sc[512];
   __shared__ float s_sh[512];
 
@@ -127,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
     const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
     okmask |= (ok ? 1u : 0u) << i;
     it_goff[i] = ok ? gy * W + gx : 0;
-    it_loff[i] = (r * C::TCOLS + c) * C::PX_V + g * 3;  // in u32x4 units
+    it_loff[i] = (r * C::TCOLS + c) * PX_V + g * NS;     // in u32x4 units
     it_g[i] = g;
   }
 
@@ -139,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
     for (int e = 0; e < 8; ++e) rin[i][e] = base[(size_t)(8 * it_g[i] + e) * HW + it_goff[i]];
   };
   auto store_item = [&](int i, int c0, u32x4* sbuf) {   // producer + split + LDS write of one staged item
-    uint32_t hi[8], mid[8], lo[8];
+    uint32_t t16[8][NS];
     const bool ok = (okmask >> i) & 1u;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -148,16 +211,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
       const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
       t *= actf * (sig - 1.0f) + 1.0f;      // SiLU when actf = 1, identity when 0
       t = ok ? t : 0.f;                     // zero padding applies to the producer's OUTPUT
-      b3_split(t, hi[e], mid[e], lo[e]);
+      if (S::SCALED) t = fminf(fmaxf(t * kH2XScale, -65504.f), 65504.f);
+      S::split(t, t16[e]);
     }
-    u32x4 vh, vm, vl;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      vh[q] = (hi[2 * q] >> 16) | hi[2 * q + 1];
-      vm[q] = (mid[2 * q] >> 16) | mid[2 * q + 1];
-      vl[q] = (lo[2 * q] >> 16) | lo[2 * q + 1];
+    for (int s = 0; s < NS; ++s) {
+      u32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = t16[2 * q][s] | (t16[2 * q + 1][s] << 16);
+      sbuf[it_loff[i] + s] = v;
     }
-    sbuf[it_loff[i]] = vh; sbuf[it_loff[i] + 1] = vm; sbuf[it_loff[i] + 2] = vl;
   };
 
   f32x16 acc[1][8];
@@ -168,37 +231,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
 
   const int nst = Cin / C::KC;
   // A fragments of this wave: [co_blk][stage][tap][split][wave][lane]
-  const u32x4* wbase = reinterpret_cast<const u32x4*>(p.w) + (size_t)co_blk * nst * 9 * 3 * 4 * 64 + wave * 64 + lane;
-  auto load_a = [&](int st, int tap, u32x4 (&a)[3]) {
-    const u32x4* q = wbase + ((size_t)st * 9 + tap) * 3 * 4 * 64;
-    a[0] = q[0]; a[1] = q[4 * 64]; a[2] = q[2 * 4 * 64];
+  const u32x4* wbase = reinterpret_cast<const u32x4*>(p.w) + (size_t)co_blk * nst * 9 * NS * 4 * 64 + wave * 64 + lane;
+  auto load_a = [&](int st, int tap, u32x4 (&a)[NS]) {
+    const u32x4* q = wbase + ((size_t)st * 9 + tap) * NS * 4 * 64;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a[s] = q[s * 4 * 64];
   };
   // B fragment base of this lane inside a stage buffer (u32x4 units): pixel (row j + dy, col l31 + dx), k-group kg
-  const int b_lane = l31 * C::PX_V + kg * 3;
+  const int b_lane = l31 * PX_V + kg * NS;
 
-  // one tap of one stage: 8 pixel fragments x 6 split products.  The three B reads of fragment j+1 are issued before
-  // the MFMAs of fragment j (order pinned with sched_barrier: left alone, the compiler sinks every LDS read to just in
-  // front of its first use and waits lgkmcnt(0) three times per fragment).
-  auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[3]) {
+  // one tap of one stage: 8 pixel fragments x NP split products.  The B reads of fragment j+1 are issued before the
+  // MFMAs of fragment j (order pinned with sched_barrier: left alone, the compiler sinks every LDS read to just in front
+  // of its first use and waits lgkmcnt(0) for each).
+  auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[NS]) {
     const int dy = tap / 3, dx = tap - 3 * dy;
-    const u32x4* sb = sbuf + b_lane + (dy * C::TCOLS + dx) * C::PX_V;
-    u32x4 bq[2][3];
-    bq[0][0] = sb[0]; bq[0][1] = sb[1]; bq[0][2] = sb[2];
+    const u32x4* sb = sbuf + b_lane + (dy * C::TCOLS + dx) * PX_V;
+    u32x4 bq[2][NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) bq[0][s] = sb[s];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j + 1 < 8) {
-        const u32x4* q = sb + (j + 1) * C::TCOLS * C::PX_V;
-        bq[(j + 1) & 1][0] = q[0]; bq[(j + 1) & 1][1] = q[1]; bq[(j + 1) & 1][2] = q[2];
+        const u32x4* q = sb + (j + 1) * C::TCOLS * PX_V;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bq[(j + 1) & 1][s] = q[s];
       }
       __builtin_amdgcn_sched_barrier(0);
-      const u32x4 bh = bq[j & 1][0], bm = bq[j & 1][1], bl = bq[j & 1][2];
       f32x16 c = acc[0][j];
-      c = mfma_32x32x16_bf16(a[2], bh, c);      // small terms first
-      c = mfma_32x32x16_bf16(a[0], bl, c);
-      c = mfma_32x32x16_bf16(a[1], bm, c);
-      c = mfma_32x32x16_bf16(a[1], bh, c);
-      c = mfma_32x32x16_bf16(a[0], bm, c);
-      c = mfma_32x32x16_bf16(a[0], bh, c);
+#pragma unroll
+      for (int k = 0; k < S::NP; ++k) c = S::mfma(a[S::pa(k)], bq[j & 1][S::pb(k)], c);
       acc[0][j] = c;
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -212,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
   for (int i = 0; i < C::NIT; ++i) store_item(i, 0, s_in0);
   __syncthreads();
 
-  u32x4 a0[3], a1[3];
+  u32x4 a0[NS], a1[NS];
   load_a(0, 0, a0);
 #pragma unroll 1
   for (int st = 0; st < nst; ++st) {
@@ -239,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_b3_kernel(ConvArgs p) {
     __syncthreads();
     // nine taps: the register sets have swapped roles (tap 8 computed from a0 and prefetched the next stage into a1)
 #pragma unroll
-    for (int s = 0; s < 3; ++s) a0[s] = a1[s];
+    for (int s = 0; s < NS; ++s) a0[s] = a1[s];
   }
 
   conv_epilogue<T, 1, 8, 4>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);

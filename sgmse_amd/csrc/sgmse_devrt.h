@@ -22,6 +22,18 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c)
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+__device__ __forceinline__ f32x16 mfma_32x32x16_f16(u32x4 a, u32x4 b, f32x16 c) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// fp32 <-> fp16 bit patterns (round to nearest even, hardware conversion)
+__device__ __forceinline__ uint32_t drt_f32_to_f16(float x) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)x); }
+__device__ __forceinline__ float drt_f16_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
+// atomic max of non-negative floats (their bit patterns order like unsigned integers)
+__device__ __forceinline__ void drt_atomic_max_nonneg(float* p, float v) {
+  atomicMax(reinterpret_cast<unsigned int*>(p), __builtin_bit_cast(unsigned int, v));
+}
+
 #define DRT_LAUNCH(kern, grid, block, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)
 

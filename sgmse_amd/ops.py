@@ -28,7 +28,7 @@ def _f32(t: Optional[torch.Tensor], name: str, dev) -> Optional[torch.Tensor]:
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
            residual: Optional[torch.Tensor] = None, out_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
            in_scale: Optional[torch.Tensor] = None, in_shift: Optional[torch.Tensor] = None, in_act: bool = False,
-           force_direct: bool = False, force_b3: bool = False) -> torch.Tensor:
+           force_direct: bool = False, force_split: Optional[str] = None) -> torch.Tensor:
     """out = (conv2d(cat[x, x2], weight, padding=k//2) + bias + residual) * out_scale, k in {1, 3};
     optional fused per-(b,c) affine (+SiLU) on the input (reference layers.py:100-124)."""
     ctx = default_context(x.device)
@@ -45,7 +45,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     ctx.use_current_stream()
     ctx.check(ctx.lib.sgmse_op_conv2d(ctx.h, x.data_ptr(), weight.data_ptr(), _lib.ptr(_f32(bias, "bias", dev)),
                                       _lib.ptr(_f32(residual, "residual", dev)), out.data_ptr(), B, Cin, Cout, H, W, kh,
-                                      float(out_scale), 2 if force_b3 else int(force_direct), _lib.ptr(_f32(in_scale, "in_scale", dev)),
+                                      float(out_scale), {None: int(force_direct), 'bf16x3': 2, 'fp16x2': 3}[force_split], _lib.ptr(_f32(in_scale, "in_scale", dev)),
                                       _lib.ptr(_f32(in_shift, "in_shift", dev)), int(in_act),
                                       _lib.ptr(_f32(x2, "x2", dev)), C2))
     return out

@@ -212,19 +212,46 @@ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
   return c;
 }
 
-// bf16 operands: 8 per lane (lane l: row/col l & 31, k group l >> 5); products are exact in fp32, the 16-term sum is
+// fp32 <-> fp16 bit patterns, round to nearest even, subnormals and infinities handled (software: g++ 11 has no _Float16)
+uint32_t f32_to_f16(float x) {
+  uint32_t u; memcpy(&u, &x, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const uint32_t absu = u & 0x7fffffffu;
+  if (absu >= 0x7f800000u) return sign | (absu > 0x7f800000u ? 0x7e00u : 0x7c00u);   // nan / inf
+  if (absu >= 0x477ff000u) return sign | 0x7c00u;                                      // rounds to >= 65520 -> inf
+  if (absu < 0x38800000u) {                                                            // below 2^-14: fp16 subnormal
+    // value = absx / 2^-24 rounded to nearest even integer
+    float ax; memcpy(&ax, &absu, 4);
+    const float scaled = ax * 16777216.0f;                                             // exact
+    const float r = nearbyintf(scaled);                                                // default mode: ties to even
+    return sign | (uint32_t)r;                                                         // r == 1024 encodes 2^-14 correctly
+  }
+  uint32_t mant = absu & 0x7fffffu, exp = (absu >> 23) - 112;                          // rebias 127 -> 15
+  uint32_t h = (exp << 10) | (mant >> 13);
+  const uint32_t rem = mant & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;                              // carries propagate into the exponent
+  return sign | h;
+}
+float f16_to_f32(uint32_t h) {
+  const uint32_t sign = (h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, mant = h & 0x3ffu;
+  float out;
+  if (exp == 0) { out = (float)mant * 5.9604644775390625e-08f; uint32_t u; memcpy(&u, &out, 4); u |= sign; memcpy(&out, &u, 4); return out; }
+  uint32_t u = exp == 31 ? (sign | 0x7f800000u | (mant << 13)) : (sign | ((exp + 112) << 23) | (mant << 13));
+  memcpy(&out, &u, 4);
+  return out;
+}
+
+// 16-bit operands: 8 per lane (lane l: row/col l & 31, k group l >> 5); products are exact in fp32, the 16-term sum is
 // formed in double and rounded once (the hardware's internal order is unspecified; tests are tolerance-based)
-f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
+template <class Widen>
+static f32x16 mfma_32x32x16_16bit(u32x4 a, u32x4 b, f32x16 c, Widen widen) {
   Worker* w = tw;
   int t = w->cur, wave = t >> 6, lane = t & 63, p = w->parity[t];
   w->parity[t] ^= 1;
   WaveState& ws = w->waves[wave];
   for (int e = 0; e < 4; ++e) {
-    uint32_t av = a[e], bv = b[e], u;
-    u = av << 16; memcpy(&ws.a8[p][lane][2 * e], &u, 4);
-    u = av & 0xffff0000u; memcpy(&ws.a8[p][lane][2 * e + 1], &u, 4);
-    u = bv << 16; memcpy(&ws.b8[p][lane][2 * e], &u, 4);
-    u = bv & 0xffff0000u; memcpy(&ws.b8[p][lane][2 * e + 1], &u, 4);
+    ws.a8[p][lane][2 * e] = widen(a[e] & 0xffffu); ws.a8[p][lane][2 * e + 1] = widen(a[e] >> 16);
+    ws.b8[p][lane][2 * e] = widen(b[e] & 0xffffu); ws.b8[p][lane][2 * e + 1] = widen(b[e] >> 16);
   }
   wave_barrier(w, wave);
   int j = lane & 31, hi = lane >> 5;
@@ -237,6 +264,10 @@ f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
   }
   return c;
 }
+f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return mfma_32x32x16_16bit(a, b, c, [](uint32_t h) { uint32_t u = h << 16; float f; memcpy(&f, &u, 4); return f; });
+}
+f32x16 mfma_32x32x16_f16(u32x4 a, u32x4 b, f32x16 c) { return mfma_32x32x16_16bit(a, b, c, [](uint32_t h) { return f16_to_f32(h); }); }
 
 f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
   Worker* w = tw;

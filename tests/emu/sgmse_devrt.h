@@ -44,6 +44,9 @@ float shfl_idx(float v, int src_lane);
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
 f32x4 mfma_16x16x4(float a, float b, f32x4 c);
 f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c);
+f32x16 mfma_32x32x16_f16(u32x4 a, u32x4 b, f32x16 c);
+uint32_t f32_to_f16(float x);
+float f16_to_f32(uint32_t h);
 }  // namespace emu
 
 #define threadIdx (emu::t_threadIdx)
@@ -56,6 +59,15 @@ static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width;
 static inline float __shfl(float v, int lane, int width = 64) { (void)width; return emu::shfl_idx(v, lane); }
 static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) { return emu::mfma_32x32x2(a, b, c); }
 static inline f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) { return emu::mfma_32x32x16_bf16(a, b, c); }
+static inline f32x16 mfma_32x32x16_f16(u32x4 a, u32x4 b, f32x16 c) { return emu::mfma_32x32x16_f16(a, b, c); }
+static inline uint32_t drt_f32_to_f16(float x) { return emu::f32_to_f16(x); }
+static inline float drt_f16_to_f32(uint32_t h) { return emu::f16_to_f32(h); }
+static inline void drt_atomic_max_nonneg(float* p, float v) {
+  uint32_t* ip = reinterpret_cast<uint32_t*>(p);
+  uint32_t nv; memcpy(&nv, &v, 4);
+  uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED);
+  while (old < nv && !__atomic_compare_exchange_n(ip, &old, nv, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
 static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) { return emu::mfma_16x16x4(a, b, c); }
 #define __builtin_amdgcn_iglp_opt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

@@ -50,7 +50,7 @@ def check_conv(dev, B, Ci, Co, H, W, ks, direct=False, dual=0, xform=False):
     assert rel_l2(out.cpu(), ref) < OP_TOL, (B, Ci, Co, H, W, ks, direct, dual, xform)
 
 
-def check_conv_b3(dev, B, Ci, Co, H, W, dual=0, xform=False):
+def check_conv_b3(dev, B, Ci, Co, H, W, dual=0, xform=False, split="bf16x3", slack=2.0):
     """The bf16x3 3x3 kernel: fp32 operands split exactly into three bf16 terms, six partial products on the bf16 MFMA
     pipe, fp32 accumulate.  Gate: the same per-op 1e-5 as the fp32 kernels against the fp32 oracle, AND an error against
     an fp64 convolution that is no worse than 2x the fp32 kernel's own (i.e. fp32 accuracy, not bf16 accuracy)."""
@@ -68,12 +68,12 @@ def check_conv_b3(dev, B, Ci, Co, H, W, dual=0, xform=False):
     x1, x2 = (x[:, :Ci - dual].contiguous(), x[:, Ci - dual:].contiguous()) if dual else (x, None)
     mv = lambda t: None if t is None else t.to(dev)
     kw = dict(residual=mv(r), out_scale=1 / math.sqrt(2.0), x2=mv(x2), in_scale=mv(sc), in_shift=mv(sh), in_act=xform)
-    out_b3 = ops.conv2d(mv(x1), mv(w), mv(b), force_b3=True, **kw).cpu()
+    out_b3 = ops.conv2d(mv(x1), mv(w), mv(b), force_split=split, **kw).cpu()
     out_f32 = ops.conv2d(mv(x1), mv(w), mv(b), **kw).cpu()
     assert rel_l2(out_b3, ref32) < OP_TOL, (B, Ci, Co, H, W, dual, xform)
     e_b3, e_f32 = rel_l2(out_b3.double(), ref64), rel_l2(out_f32.double(), ref64)
-    print(f"conv_b3 {Ci}->{Co} @{B}x{H}x{W}: error vs fp64  bf16x3 {e_b3:.2e}  fp32-MFMA {e_f32:.2e}  torch-fp32 {rel_l2(ref32.double(), ref64):.2e}")
-    assert e_b3 < max(2 * e_f32, 3e-7), (e_b3, e_f32)
+    print(f"conv_split {Ci}->{Co} @{B}x{H}x{W}: error vs fp64  {split} {e_b3:.2e}  fp32-MFMA {e_f32:.2e}  torch-fp32 {rel_l2(ref32.double(), ref64):.2e}")
+    assert e_b3 < max(slack * e_f32, 3e-7), (split, e_b3, e_f32)
 
 
 def check_groupnorm(dev, B, C, H, W, act=True, dual=0):

@@ -66,6 +66,15 @@ def test_conv3x3_bf16x3_kernel_has_fp32_accuracy(hip):
     P.check_conv_b3(hip, 1, 512, 256, 16, 32, dual=256, xform=True)
 
 
+def test_conv3x3_fp16x2_kernel_is_within_one_bit_of_fp32(hip):
+    P.check_conv_b3(hip, 1, 32, 128, 9, 33, xform=True, split="fp16x2", slack=3.0)
+    P.check_conv_b3(hip, 2, 48, 128, 8, 32, xform=True, split="fp16x2", slack=3.0)
+    P.check_conv_b3(hip, 1, 64, 256, 5, 40, dual=32, xform=True, split="fp16x2", slack=3.0)
+    P.check_conv_b3(hip, 2, 128, 128, 64, 96, xform=True, split="fp16x2", slack=3.0)
+    P.check_conv_b3(hip, 1, 384, 128, 32, 64, dual=128, xform=True, split="fp16x2", slack=3.0)
+    P.check_conv_b3(hip, 1, 512, 256, 16, 32, dual=256, xform=True, split="fp16x2", slack=3.0)
+
+
 def test_forward_with_bf16x3_on_every_eligible_layer(hip):
     P.check_forward_b3_everywhere(hip)
 
