@@ -6,7 +6,7 @@
 #include "kernels_conv_b3.h"
 
 #ifndef SGMSE_CONV_SPLIT_DEFAULT
-#define SGMSE_CONV_SPLIT_DEFAULT 1     // 0: fp32 MFMA everywhere, 1: bf16x3 on the wide levels, 2: fp16x2 on the wide levels
+#define SGMSE_CONV_SPLIT_DEFAULT 2     // 0: fp32 MFMA everywhere, 1: bf16x3 on the wide levels, 2: fp16x2 on the wide levels
 #endif
 #ifndef SGMSE_CONV_PIPE_DEFAULT
 #define SGMSE_CONV_PIPE_DEFAULT 1
