@@ -8,9 +8,12 @@ full 65.6 M-parameter NCSN++, fp32, random-init weights).  N > 1: one process pe
 rank enhances its own batch (weak scaling), the only collective is one weight broadcast before the timed region.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     dominant kernel = conv3x3 fp32 MFMA implicit GEMM (128-channel x 256-pixel tile); achieved = algorithmic
-               FLOPs of its launches / their HIP-event time, measured by one instrumented (eager) network evaluation on
-               the same batch right after the timed region; peak = 157.3 TFLOP/s fp32 (MI355X_MICROARCH.md)
+  roofline     dominant kernel = the 3x3 convolution of the wide U-Net levels (128-channel x 256-pixel tile): by default
+               the fp16x2 split kernel (fp32 operands as two fp16 terms, three partial products on the f16 MFMA pipe, fp32
+               accumulate; kernels_conv_b3.h).  achieved = ALGORITHMIC fp32 FLOPs of its launches / their HIP-event time,
+               measured by one instrumented (eager) network evaluation on the same batch right after the timed region;
+               peak = the dense MFMA peak of the instruction used divided by the partial products per algorithmic
+               multiply: 2500/3 (fp16x2), 2500/6 (bf16x3), 157.3 (fp32 MFMA) TFLOP/s (MI355X_MICROARCH.md)
   cpu_baseline the CPU oracle (oracle/, a torch-fp32 restatement of the reference) timed on this box's host cores on
                a bounded sample, extrapolated to the 60-evaluation run
 """
@@ -26,6 +29,15 @@ if ROOT not in sys.path:
 
 FLOP_PER_EVAL = 1.064686e12       # algorithmic FLOPs of one NCSN++ evaluation at [1,4,256,512]
 FP32_PEAK_TFLOPS = 157.3
+MFMA16_PEAK_TFLOPS = 2500.0       # dense bf16 / f16 MFMA
+DOMINANT = {   # conv split mode -> (kernel, effective peak, how the peak is derived, kernel-name prefix in rocprof output)
+    0: ("conv_mfma_pipe_kernel<3,2,2,4> (3x3 fp32 MFMA implicit GEMM, 128 co x 256 px tile)", FP32_PEAK_TFLOPS,
+        "fp32 MFMA peak", "void sgmse::conv_mfma_kernel<3, 2, 2, 4"),
+    1: ("conv3x3_split_kernel<SplitB3> (3x3 implicit GEMM, exact 3-way bf16 operand split, 6 partial products, fp32 accumulate)",
+        MFMA16_PEAK_TFLOPS / 6, "dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per multiply", "void sgmse::conv3x3_split_kernel<sgmse::SplitB3>"),
+    2: ("conv3x3_split_kernel<SplitH2> (3x3 implicit GEMM, fp16x2 operand split, 3 partial products, fp32 accumulate)",
+        MFMA16_PEAK_TFLOPS / 3, "dense f16 MFMA peak 2500 TFLOP/s / 3 partial products per multiply", "void sgmse::conv3x3_split_kernel<sgmse::SplitH2>"),
+}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -103,21 +115,20 @@ def cpu_baseline(state, n_evals, N, snr, frames=128):
             "seconds_per_eval": t_eval, "rtf": per_utt / 4.0}
 
 
-def hbm_traffic_of_dominant_kernel():
+def hbm_traffic_of_dominant_kernel(prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
     separate passes, read side calibrated x2 in the same run; tools/summarize_hbm.py).  rocprofv3 --pmc segfaults on the
     full bench command, so the counters are collected on the kernel micro-benchmark at the dominant layer shape."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")))
-    if not files:
-        return None, "no PMC profile committed"
-    d = json.load(open(files[-1]))
-    for k, v in d.items():
-        if k.startswith("void sgmse::conv_mfma_kernel<3, 2, 2, 4"):
-            alg = d.get("_algorithmic_bytes_per_launch_of_the_benchmarked_conv")
-            return v["hbm_bytes_per_launch"], (f"{os.path.basename(files[-1])}: 3x3 128->128 @256x512, B=8, fused producer+residual epilogue; "
-                                               f"algorithmic bytes of that launch = {alg:.4g}" if alg else os.path.basename(files[-1]))
-    return None, "dominant kernel not in " + os.path.basename(files[-1])
+    for f in reversed(files):
+        d = json.load(open(f))
+        for k, v in d.items():
+            if k.startswith(prefix):
+                alg = d.get("_algorithmic_bytes_per_launch_of_the_benchmarked_conv")
+                note = f"{os.path.basename(f)}: 3x3 128->128 @256x512, B=8, fused producer+residual epilogue"
+                return v["hbm_bytes_per_launch"], note + (f"; algorithmic bytes of that launch = {alg:.4g}" if alg else "")
+    return None, "no committed PMC profile holds the dominant kernel"
 
 
 def main():
@@ -223,10 +234,11 @@ def main():
             prof, _ = ctx.profile_forward(Y, tt)
             dom = prof["conv3x3_mfma_128x256"]
             ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-            traffic, traffic_note = hbm_traffic_of_dominant_kernel()
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-                               "kernel": "conv_mfma_pipe_kernel<3,2,2,4> (3x3 fp32 MFMA implicit GEMM, 128 co x 256 px tile)",
+            kname, peak, peak_note, prefix = DOMINANT[ctx.conv_split_mode()]
+            traffic, traffic_note = hbm_traffic_of_dominant_kernel(prefix)
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": traffic, "traffic_note": traffic_note,
+                               "kernel": kname, "peak_note": peak_note, "achieved_vs_fp32_mfma_peak": ach / FP32_PEAK_TFLOPS,
                                "launches_per_eval": dom["launches"],
                                "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),
                                "flop_per_launch_avg": dom["work"] / max(dom["launches"], 1)}

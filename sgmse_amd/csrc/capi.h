@@ -168,6 +168,11 @@ int sgmse_op_groupnorm(sgmse_ctx* ctx, const float* x, const float* gamma, const
   return sg_guard(ctx, [&](sgmse::Engine& e) { e.op_groupnorm(x, gamma, beta, out, B, C, H, W, act, x2, C2); });
 }
 
+int sgmse_conv_split_mode(sgmse_ctx* ctx, int* out) {
+  SG_ARG(ctx, out != nullptr, "out is null");
+  return sg_guard(ctx, [&](sgmse::Engine& e) { *out = e.split_mode(); });
+}
+
 int sgmse_op_fir(sgmse_ctx* ctx, const float* x, float* out, int BC, int H, int W, int up, const float* in_scale,
                  const float* in_shift, int in_act, float* out_raw) {
   SG_ARG(ctx, x && out && BC > 0 && H > 0 && W > 0, "null pointer or non-positive shape");

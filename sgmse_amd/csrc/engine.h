@@ -482,6 +482,7 @@ class Engine {
     nfe_ = N;
   }
   int last_nfe() const { return nfe_; }
+  int split_mode() const { return split_mode_; }
   size_t arena_bytes() const { return arena_cap_; }
 
   // ---- single ops (op-level C ABI + tests) ------------------------------------------------------------------

@@ -34,7 +34,7 @@ fi
 if has hbm; then
   echo "== HBM traffic of the dominant kernel (FETCH_SIZE / WRITE_SIZE passes; rocprofv3 --pmc segfaults on the full bench command)"
   rm -rf gpurun_out/hbm
-  export VARIANTS=-1 ROUNDS=1 SHAPES=0 FUSED=1 CALIB=1 OUT=hbm_microbench.json
+  export VARIANTS=${HBM_VARIANTS:-128} ROUNDS=1 SHAPES=0 FUSED=1 CALIB=1 OUT=hbm_microbench.json
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/hbm/fetch -o p -- python tools/conv_microbench.py > gpurun_out/hbm_fetch.log 2>&1; echo "fetch rc=$?"
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/hbm/write -o p -- python tools/conv_microbench.py > gpurun_out/hbm_write.log 2>&1; echo "write rc=$?"
   unset VARIANTS ROUNDS SHAPES FUSED CALIB OUT
