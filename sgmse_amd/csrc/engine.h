@@ -866,7 +866,9 @@ class Engine {
   }
 
   // ---- op wrappers used by the forward ------------------------------------------------------------------------
-  struct Xform { const float* scale = nullptr; const float* shift = nullptr; int act = 0; };
+  // fused producer of a consumer's input.  `bounded`: no producer here, but the tensor IS the (FIR-resampled) output of a
+  // GroupNorm+SiLU producer applied upstream, i.e. O(1) like a producer's output -- what the fp16x2 kernel presumes
+  struct Xform { const float* scale = nullptr; const float* shift = nullptr; int act = 0; bool bounded = false; };
 
   void tick(int cls, double work, int launches = 1) {
     if (!prof_) return;
@@ -943,7 +945,7 @@ class Engine {
     // its results differ from the fp32-MFMA kernels in the last bits and an utterance must not depend on its batch.
     const bool use_b3 = use_mfma && w.packed_split && conv_b3_eligible(w.ks, a.C, b ? b->C : 0, w.cout) &&
                         (long)((a.H + 7) / 8) * ((a.W + 31) / 32) >= b3_min_tiles_ &&
-                        (split_mode_ != 2 || xf.scale != nullptr);   // fp16x2 presumes the O(1) output of a GroupNorm producer
+                        (split_mode_ != 2 || xf.scale != nullptr || xf.bounded);   // fp16x2 presumes the O(1) output of a GroupNorm producer
     if (emit_stats && use_mfma && fuse_gn_stats_) {
       o.nsub = conv_plan_nsub(a.H, a.W);
       o.st = arena_.alloc((size_t)B_ * w.cout * o.nsub * 2);
@@ -1016,7 +1018,7 @@ class Engine {
       SG_REQUIRE(b == nullptr, "resample block with concat input");
       Tensor hr = fir(a, m.up, x0, &xs);
       have_xs = true;
-      h = conv(r.c0, hr, nullptr, Xform{}, nullptr, temb, nullptr, 1.f, ctl, true);
+      h = conv(r.c0, hr, nullptr, Xform{nullptr, nullptr, 0, true}, nullptr, temb, nullptr, 1.f, ctl, true);
       drop(hr);
     } else {
       h = conv(r.c0, a, b, x0, nullptr, temb, nullptr, 1.f, ctl, true);
