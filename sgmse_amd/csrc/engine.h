@@ -1214,10 +1214,10 @@ class Engine {
     split_mode_ = e ? atoi(e) : SGMSE_CONV_SPLIT_DEFAULT;
     SG_REQUIRE(split_mode_ >= 0 && split_mode_ <= 2, "SGMSE_CONV_SPLIT must be 0, 1 or 2");
     e = getenv("SGMSE_B3_MIN_TILES");
-    b3_min_tiles_ = e ? atol(e) : 32L;                   // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
+    b3_min_tiles_ = e ? atol(e) : 8L;                    // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
   }
-  long tile_min_blocks_ = 512, b3_min_tiles_ = 32;
+  long tile_min_blocks_ = 512, b3_min_tiles_ = 8;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};

@@ -34,6 +34,12 @@
 #pragma once
 #include "kernels_conv.h"
 
+// scheduling fence between the operand reads and the MFMAs of a pixel fragment: 0 pins everything (0x6, letting VALU /
+// SALU instructions move across, changes nothing: the compiler still clusters the producer arithmetic behind the MFMAs)
+#ifndef SGMSE_SPLIT_FENCE
+#define SGMSE_SPLIT_FENCE 0
+#endif
+
 namespace sgmse {
 
 struct SplitB3 {
@@ -223,6 +229,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     }
   };
 
+  // the same, one ELEMENT at a time: the eight elements of an item are spread over the eight pixel fragments of a tap
+  // (one per fragment, behind that fragment's MFMAs and inside its scheduling fences), so that the producer arithmetic
+  // issues while the MFMA pipe works instead of after the tap
+  u32x4 pk[NS];
+  uint32_t ev[NS];
+  auto stage_elem = [&](int i, int e, int c0) {
+    const bool ok = (okmask >> i) & 1u;
+    const int ch = c0 + 8 * it_g[i] + e;
+    float t = rin[i][e] * s_sc[ch] + s_sh[ch];
+    const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+    t *= actf * (sig - 1.0f) + 1.0f;
+    t = ok ? t : 0.f;
+    if (S::SCALED) t = fminf(fmaxf(t * kH2XScale, -65504.f), 65504.f);
+    uint32_t t16[NS];
+    S::split(t, t16);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if ((e & 1) == 0) ev[s] = t16[s]; else pk[s][e >> 1] = ev[s] | (t16[s] << 16);
+    }
+  };
+  auto flush_item = [&](int i, u32x4* sbuf) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sbuf[it_loff[i] + s] = pk[s];
+  };
+
   f32x16 acc[1][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -243,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   // one tap of one stage: 8 pixel fragments x NP split products.  The B reads of fragment j+1 are issued before the
   // MFMAs of fragment j (order pinned with sched_barrier: left alone, the compiler sinks every LDS read to just in front
   // of its first use and waits lgkmcnt(0) for each).
-  auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[NS]) {
+  auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[NS], int item, int c0n, u32x4* nxt) {
     const int dy = tap / 3, dx = tap - 3 * dy;
     const u32x4* sb = sbuf + b_lane + (dy * C::TCOLS + dx) * PX_V;
     u32x4 bq[2][NS];
@@ -256,12 +287,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) bq[(j + 1) & 1][s] = q[s];
       }
-      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(SGMSE_SPLIT_FENCE);
       f32x16 c = acc[0][j];
 #pragma unroll
       for (int k = 0; k < S::NP; ++k) c = S::mfma(a[S::pa(k)], bq[j & 1][S::pb(k)], c);
       acc[0][j] = c;
-      __builtin_amdgcn_sched_barrier(0);
+      if (item >= 0) {
+        stage_elem(item, j, c0n);
+        if (j == 7) flush_item(item, nxt);
+      }
+      __builtin_amdgcn_sched_barrier(SGMSE_SPLIT_FENCE);
     }
   };
 
@@ -292,10 +327,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       if (tap & 1) load_a(nstg, ntap, a0); else load_a(nstg, ntap, a1);
       if (tap < C::NIT) load_item(tap, stn * C::KC);
       __builtin_amdgcn_sched_barrier(0);
-      if (tap & 1) compute_tap(cur, tap, a1); else compute_tap(cur, tap, a0);
-      // (slicing this producer work between the MFMAs with sched_group_barrier was tried: the compiler pairs the
-      // elements into packed-f32 ops, clusters them behind the MFMAs anyway and spills)
-      if (tap >= 4 && (tap & 1) == 0) store_item((tap - 4) / 2, stn * C::KC, nxt);
+      const int item = (tap >= 4 && (tap & 1) == 0) ? (tap - 4) / 2 : -1;     // taps 4, 6, 8 stage items 0, 1, 2
+      if (tap & 1) compute_tap(cur, tap, a1, item, stn * C::KC, nxt); else compute_tap(cur, tap, a0, item, stn * C::KC, nxt);
     }
     __syncthreads();
     // nine taps: the register sets have swapped roles (tap 8 computed from a0 and prefetched the next stage into a1)
