@@ -78,11 +78,16 @@ inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt:
 
 // bf16x3 3x3 convolution (kernels_conv_b3.h); a.w = weights packed by pack_weights_b3_kernel
 inline bool conv_b3_eligible(int ks, int C1, int C2, int Cout) {
-  return ks == 3 && Cout % 128 == 0 && (C1 + C2) % 16 == 0 && (C2 == 0 || C1 % 16 == 0) && (C1 + C2) <= 512;
+  return (ks == 3 || ks == 1) && Cout % 128 == 0 && (C1 + C2) % 16 == 0 && (C2 == 0 || C1 % 16 == 0) && (C1 + C2) <= 512;
 }
 // mode 1: bf16x3, mode 2: fp16x2 (a.acc_scale must point at the factor stored behind the packed weights)
-inline void launch_conv_split(const ConvArgs& a, int mode, drt::stream_t st) {
+inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t st) {
   const int tiles = a.B * ((a.H + 7) / 8) * ((a.W + 31) / 32);
+  if (ks == 1) {
+    if (mode == 2) DRT_LAUNCH(conv1x1_split_kernel<SplitH2>, dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
+    else DRT_LAUNCH(conv1x1_split_kernel<SplitB3>, dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
+    return;
+  }
   if (mode == 2) DRT_LAUNCH(conv3x3_split_kernel<SplitH2>, dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
   else DRT_LAUNCH(conv3x3_split_kernel<SplitB3>, dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
 }

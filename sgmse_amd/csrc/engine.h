@@ -235,6 +235,7 @@ struct ConvW {            // one convolution's parameters on the device
   const float* packed_split = nullptr; // split-kernel fragment layout (kernels_conv_b3.h) in the engine's split mode,
                                        // 3x3 with cout % 128 == 0, cin % 16 == 0
   const float* split_scale = nullptr;  // fp16x2: device scalar 2^-(k+4) behind the packed fragments
+  int split_mode = 0;                  // 1 bf16x3, 2 fp16x2 (0: no split layout)
   const float* bias = nullptr;
   int ks = 1, cin = 0, cout = 0, co_t = 0;
 };
@@ -495,9 +496,9 @@ class Engine {
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
     if (force_direct == 2 || force_direct == 3) {          // the split kernels: 2 bf16x3, 3 fp16x2
       SG_REQUIRE(conv_b3_eligible(ks, a.C1, C2, Cout), "op_conv2d: shape is not eligible for the split kernels");
-      const float* pk = pack_split(w_oihw, Cin, Cout, force_direct - 1, false, &a.acc_scale);
+      const float* pk = pack_split(w_oihw, ks, Cin, Cout, force_direct - 1, false, &a.acc_scale);
       a.w = pk;
-      launch_conv_split(a, force_direct - 1, stream_);
+      launch_conv_split(a, ks, force_direct - 1, stream_);
       SG_CHECK(drt::stream_sync(stream_));
       free_tmp(const_cast<float*>(pk));
     } else if (pl.mfma && !force_direct && (C2 == 0 || a.C1 % ((ks == 3) ? 8 : 32) == 0)) {
@@ -617,8 +618,8 @@ class Engine {
     drt::event_t e0{}, e1{};
     drt::event_create(&e0); drt::event_create(&e1);
     const float* pk3 = nullptr;
-    if (b3) { pk3 = pack_split(w, Cin, Cout, smode, false, &a.acc_scale); a.w = pk3; }
-    auto go = [&]() { if (b3) launch_conv_split(a, smode, stream_); else launch_conv_mfma(a, ks, pl, stream_, variant); };
+    if (b3) { pk3 = pack_split(w, ks, Cin, Cout, smode, false, &a.acc_scale); a.w = pk3; }
+    auto go = [&]() { if (b3) launch_conv_split(a, ks, smode, stream_); else launch_conv_mfma(a, ks, pl, stream_, variant); };
     for (int i = 0; i < 2; ++i) go();
     drt::event_record(&e0, stream_);
     for (int i = 0; i < iters; ++i) go();
@@ -717,21 +718,26 @@ class Engine {
         c.packed32 = pk32;
       }
     }
-    if (split_mode_ && conv_b3_eligible(ks, cin, 0, cout)) c.packed_split = pack_split(c.oihw, cin, cout, split_mode_, true, &c.split_scale);
+    // 3x3: the engine's split mode; 1x1 (raw residual-stream inputs of unknown range): always the range-free bf16x3
+    if (split_mode_ && conv_b3_eligible(ks, cin, 0, cout)) {
+      c.split_mode = ks == 3 ? split_mode_ : 1;
+      c.packed_split = pack_split(c.oihw, ks, cin, cout, c.split_mode, true, &c.split_scale);
+    }
     return c;
   }
 
   // weights in the fragment order of conv3x3_split_kernel (mode 1: bf16x3, 2: fp16x2 with the layer's power-of-two scale)
-  const float* pack_split(const float* oihw, int cin, int cout, int mode, bool weight_owned, const float** scale_out) {
-    const size_t frags = mode == 2 ? packed_split_frags<SplitH2>(cin, cout) : packed_split_frags<SplitB3>(cin, cout);
+  const float* pack_split(const float* oihw, int ks, int cin, int cout, int mode, bool weight_owned, const float** scale_out) {
+    const int taps = ks * ks;
+    const size_t frags = mode == 2 ? packed_split_frags<SplitH2>(cin, cout, taps) : packed_split_frags<SplitB3>(cin, cout, taps);
     const size_t bytes = frags * 16 + 16;
     uint32_t* pk = static_cast<uint32_t*>(weight_owned ? dev_alloc_w(bytes) : dev_alloc_tmp(bytes));
-    PackSplitArgs pa{oihw, pk, cin, cout, frags, nullptr};
+    PackSplitArgs pa{oihw, pk, cin, cout, frags, nullptr, taps};
     const dim3 grid((unsigned)((frags + 255) / 256));
     if (mode == 2) {
       float* amax = reinterpret_cast<float*>(pk) + frags * 4 + 1;     // scratch word behind the scale
       SG_CHECK(drt::memset_dev(amax, 0, 4, stream_));
-      const size_t n = (size_t)cout * cin * 9;
+      const size_t n = (size_t)cout * cin * taps;
       DRT_LAUNCH(absmax_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), stream_, oihw, n, amax);
       pa.absmax = amax;
       DRT_LAUNCH(pack_weights_split_kernel<SplitH2>, grid, dim3(256), stream_, pa);
@@ -764,6 +770,10 @@ class Engine {
       for (int s = 0; s < nsrc; ++s) pa.src[s] = Wp(pre + "NIN_" + std::to_string(which[s]) + ".W");
       DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, pa);
       c.packed = pk;
+    }
+    if (split_mode_ && conv_b3_eligible(1, C, 0, c.cout)) {
+      c.split_mode = 1;
+      c.packed_split = pack_split(c.oihw, 1, C, c.cout, 1, true, &c.split_scale);
     }
     return c;
   }
@@ -945,7 +955,7 @@ class Engine {
     // its results differ from the fp32-MFMA kernels in the last bits and an utterance must not depend on its batch.
     const bool use_b3 = use_mfma && w.packed_split && conv_b3_eligible(w.ks, a.C, b ? b->C : 0, w.cout) &&
                         (long)((a.H + 7) / 8) * ((a.W + 31) / 32) >= b3_min_tiles_ &&
-                        (split_mode_ != 2 || xf.scale != nullptr || xf.bounded);   // fp16x2 presumes the O(1) output of a GroupNorm producer
+                        (w.split_mode != 2 || xf.scale != nullptr || xf.bounded);   // fp16x2 presumes the O(1) output of a GroupNorm producer
     if (emit_stats && use_mfma && fuse_gn_stats_) {
       o.nsub = conv_plan_nsub(a.H, a.W);
       o.st = arena_.alloc((size_t)B_ * w.cout * o.nsub * 2);
@@ -962,10 +972,10 @@ class Engine {
     const double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
     if (use_b3) {
       ca.w = w.packed_split; ca.acc_scale = w.split_scale;
-      launch_conv_split(ca, split_mode_, stream_);
+      launch_conv_split(ca, w.ks, w.split_mode, stream_);
       if (prof_ && prof_dump_)
         snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "");
-      tick(TC_CONV3_BIG, fl);
+      tick(w.ks == 3 ? TC_CONV3_BIG : TC_CONV1, fl);
     } else if (use_mfma) {
       ConvPlan pl{co_t, rows_, true};
       ca.w = (co_t == w.co_t) ? w.packed : w.packed32;

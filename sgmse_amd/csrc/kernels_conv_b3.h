@@ -82,10 +82,10 @@ struct ConvSplitGeom {
   static constexpr int NIT = (NITEM + 255) / 256;              // per thread (3)
 };
 
-// Weight packing.  src: OIHW fp32 [Cout][Cin][3][3]; dst: u32x4 [nCoBlk][Cin/16][9][NS][4][64], followed (SplitH2) by
+// Weight packing.  src: OIHW fp32 [Cout][Cin][k][k] (taps = k*k = 9 or 1); dst: u32x4 [nCoBlk][Cin/16][taps][NS][4][64], followed (SplitH2) by
 // one float: the factor 2^-(k+4) that takes the accumulator back to the unscaled convolution.  `absmax` (device,
 // SplitH2 only) = max |w| of the layer, from absmax_kernel.  One thread per 16-byte fragment element.
-struct PackSplitArgs { const float* src; uint32_t* dst; int cin, cout; size_t total; const float* absmax; };
+struct PackSplitArgs { const float* src; uint32_t* dst; int cin, cout; size_t total; const float* absmax; int taps; };
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t n, float* out) {   // *out zeroed by the caller
   float m = 0.f;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(PackSplitArgs p
   size_t r = e >> 6;
   const int w = (int)(r & 3); r >>= 2;
   const int split = (int)(r % S::NS); r /= S::NS;
-  const int tap = (int)(r % 9); r /= 9;
+  const int tap = (int)(r % p.taps); r /= p.taps;
   const int nst = p.cin / 16;
   const int st = (int)(r % nst);
   const int blk = (int)(r / nst);
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(PackSplitArgs p
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int c = c0 + 2 * q + h;
-      const float v = (co < p.cout ? p.src[((size_t)co * p.cin + c) * 9 + tap] : 0.f) * wscale;
+      const float v = (co < p.cout ? p.src[((size_t)co * p.cin + c) * p.taps + tap] : 0.f) * wscale;
       uint32_t t[S::NS];
       S::split(v, t);
       uint32_t sel = t[0];
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(PackSplitArgs p
 }
 
 template <class S>
-inline size_t packed_split_frags(int cin, int cout) { return (size_t)((cout + 127) / 128) * (cin / 16) * 9 * S::NS * 4 * 64; }
+inline size_t packed_split_frags(int cin, int cout, int taps = 9) { return (size_t)((cout + 127) / 128) * (cin / 16) * taps * S::NS * 4 * 64; }
 template <class S>
 inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<S>(cin, cout) * 16 + 16; }
 
@@ -334,6 +334,157 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     // nine taps: the register sets have swapped roles (tap 8 computed from a0 and prefetched the next stage into a1)
 #pragma unroll
     for (int s = 0; s < NS; ++s) a0[s] = a1[s];
+  }
+
+  conv_epilogue<T, 1, 8, 4>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1x1 convolution (residual shortcuts `Conv_2`, NIN; reference layerspp.py:241-243, layers.py:537-555) with the same
+// operand split.  Same workgroup shape and operand paths as the 3x3 kernel (wave = 32 output channels x 8 pixel
+// fragments, B through LDS, A from global), but a K-stage is only one MFMA K-step deep (16 channels, no taps), so the
+// global loads of a stage are issued TWO stages ahead (register sets rinA / rinB) and the producer + split of stage
+// s+1 is spread over the pixel fragments of stage s.  Inputs of these layers are raw residual-stream activations of
+// unknown range: the engine uses the range-free bf16x3 policy here.
+template <class S>
+__global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
+  using T = ConvTile<1, 4, 1, 8, 1>;
+  static_assert(T::CO_T == 128 && T::ROWS == 8, "tile");
+  constexpr int NS = S::NS, PX_V = S::PX_V, KC = 16, NIT = 2;     // 256 px x 2 k-groups = 512 items = 2 per thread
+  constexpr int STAGE_V = 256 * PX_V;
+  __shared__ u32x4 s_in0[STAGE_V];
+  __shared__ u32x4 s_in1[STAGE_V];
+  __shared__ float s_sc[512];
+  __shared__ float s_sh[512];
+
+  const int tid = threadIdx.x;
+  const int Cin = p.C1 + p.C2;
+  const int H = p.H, W = p.W;
+  const int tiles_x = (W + 31) >> 5;
+  const int tiles_y = (H + 7) >> 3;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int co_blk = blockIdx.y;
+  const int x0 = tx * 32, y0 = ty * 8;
+  const bool xform = p.in_scale != nullptr;
+  for (int c = tid; c < Cin; c += 256) {
+    s_sc[c] = xform ? p.in_scale[b * Cin + c] : 1.f;
+    s_sh[c] = xform ? p.in_shift[b * Cin + c] : 0.f;
+  }
+  const float actf = (xform && p.in_act) ? 1.f : 0.f;
+  const size_t HW = (size_t)H * W;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
+
+  // staging items: (k-group g, row r, column c), c fastest; pixels outside the image are clamped (their outputs are
+  // never stored and a 1x1 convolution does not mix pixels)
+  int it_goff[NIT], it_loff[NIT], it_g[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int it = tid + 256 * i;
+    const int g = it >> 8, r = (it >> 5) & 7, c = it & 31;
+    int gy = y0 + r, gx = x0 + c;
+    gy = gy < H ? gy : H - 1; gx = gx < W ? gx : W - 1;
+    it_goff[i] = gy * W + gx;
+    it_loff[i] = (r * 32 + c) * PX_V + g * NS;
+    it_g[i] = g;
+  }
+  float rinA[NIT][8], rinB[NIT][8];
+  auto load_items = [&](int c0, float (&dst)[NIT][8]) {
+    const bool first = c0 < p.C1;
+    const float* base = first ? p.src1 + ((size_t)b * p.C1 + c0) * HW : p.src2 + ((size_t)b * p.C2 + (c0 - p.C1)) * HW;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[i][e] = base[(size_t)(8 * it_g[i] + e) * HW + it_goff[i]];
+  };
+  u32x4 pk[NS];
+  uint32_t ev[NS];
+  auto stage_elem = [&](int i, int e, int c0, const float (&src)[NIT][8]) {
+    const int ch = c0 + 8 * it_g[i] + e;
+    float t = src[i][e] * s_sc[ch] + s_sh[ch];
+    const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+    t *= actf * (sig - 1.0f) + 1.0f;
+    if (S::SCALED) t = fminf(fmaxf(t * kH2XScale, -65504.f), 65504.f);
+    uint32_t t16[NS];
+    S::split(t, t16);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if ((e & 1) == 0) ev[s] = t16[s]; else pk[s][e >> 1] = ev[s] | (t16[s] << 16);
+    }
+  };
+  auto flush_item = [&](int i, u32x4* sbuf) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sbuf[it_loff[i] + s] = pk[s];
+  };
+
+  f32x16 acc[1][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+  const int nst = Cin / KC;
+  const u32x4* wbase = reinterpret_cast<const u32x4*>(p.w) + (size_t)co_blk * nst * NS * 4 * 64 + wave * 64 + lane;
+  auto load_a = [&](int st, u32x4 (&a)[NS]) {
+    const u32x4* q = wbase + (size_t)st * NS * 4 * 64;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a[s] = q[s * 4 * 64];
+  };
+  const int b_lane = l31 * PX_V + kg * NS;
+
+  // prologue: stage 0 -> LDS, stage 1 -> rinA
+  load_items(0, rinA);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) stage_elem(i, e, 0, rinA);
+    flush_item(i, s_in0);
+  }
+  load_items((nst > 1 ? 1 : 0) * KC, rinA);
+  u32x4 a0[NS], a1[NS];
+  load_a(0, a0);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int st = 0; st < nst; ++st) {
+    const int st1 = st + 1 < nst ? st + 1 : st, st2 = st + 2 < nst ? st + 2 : nst - 1;   // clamped: branch-free tail
+    const u32x4* cur = (st & 1) ? s_in1 : s_in0;
+    u32x4* nxt = (st & 1) ? s_in0 : s_in1;
+    load_a(st1, a1);                    // older than the HBM loads below (vmcnt retires in order)
+    load_items(st2 * KC, rinB);
+    __builtin_amdgcn_sched_barrier(0);
+    const u32x4* sb = cur + b_lane;
+    u32x4 bq[2][NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) bq[0][s] = sb[s];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j + 1 < 8) {
+        const u32x4* q = sb + (j + 1) * 32 * PX_V;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bq[(j + 1) & 1][s] = q[s];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 c = acc[0][j];
+#pragma unroll
+      for (int k = 0; k < S::NP; ++k) c = S::mfma(a0[S::pa(k)], bq[j & 1][S::pb(k)], c);
+      acc[0][j] = c;
+      // stage st+1 (raw values in rinA): item j / 4, elements 2 (j % 4) and 2 (j % 4) + 1
+      stage_elem(j >> 2, 2 * (j & 3), st1 * KC, rinA);
+      stage_elem(j >> 2, 2 * (j & 3) + 1, st1 * KC, rinA);
+      if ((j & 3) == 3) flush_item(j >> 2, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a0[s] = a1[s];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rinA[i][e] = rinB[i][e];
   }
 
   conv_epilogue<T, 1, 8, 4>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);

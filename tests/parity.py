@@ -50,21 +50,21 @@ def check_conv(dev, B, Ci, Co, H, W, ks, direct=False, dual=0, xform=False):
     assert rel_l2(out.cpu(), ref) < OP_TOL, (B, Ci, Co, H, W, ks, direct, dual, xform)
 
 
-def check_conv_b3(dev, B, Ci, Co, H, W, dual=0, xform=False, split="bf16x3", slack=2.0):
+def check_conv_b3(dev, B, Ci, Co, H, W, dual=0, xform=False, split="bf16x3", slack=2.0, ks=3):
     """The bf16x3 3x3 kernel: fp32 operands split exactly into three bf16 terms, six partial products on the bf16 MFMA
     pipe, fp32 accumulate.  Gate: the same per-op 1e-5 as the fp32 kernels against the fp32 oracle, AND an error against
     an fp64 convolution that is no worse than 2x the fp32 kernel's own (i.e. fp32 accuracy, not bf16 accuracy)."""
     from sgmse_amd import ops
     g = gen(B * 1000 + Ci + Co + H + W)
-    x = R(g, B, Ci, H, W); w = R(g, Co, Ci, 3, 3) / math.sqrt(Ci * 9); b = R(g, Co); r = R(g, B, Co, H, W)
+    x = R(g, B, Ci, H, W); w = R(g, Co, Ci, ks, ks) / math.sqrt(Ci * ks * ks); b = R(g, Co); r = R(g, B, Co, H, W)
     sc = sh = None
     xin = x
     if xform:
         sc, sh = R(g, B, Ci), R(g, B, Ci)
         xin = x * sc[:, :, None, None] + sh[:, :, None, None]
         xin = xin * torch.sigmoid(xin)
-    ref32 = (F.conv2d(xin, w, b, padding=1) + r) / math.sqrt(2.0)
-    ref64 = (F.conv2d(xin.double(), w.double(), b.double(), padding=1) + r.double()) / math.sqrt(2.0)
+    ref32 = (F.conv2d(xin, w, b, padding=ks // 2) + r) / math.sqrt(2.0)
+    ref64 = (F.conv2d(xin.double(), w.double(), b.double(), padding=ks // 2) + r.double()) / math.sqrt(2.0)
     x1, x2 = (x[:, :Ci - dual].contiguous(), x[:, Ci - dual:].contiguous()) if dual else (x, None)
     mv = lambda t: None if t is None else t.to(dev)
     kw = dict(residual=mv(r), out_scale=1 / math.sqrt(2.0), x2=mv(x2), in_scale=mv(sc), in_shift=mv(sh), in_act=xform)

@@ -66,6 +66,16 @@ def test_conv3x3_bf16x3_kernel_has_fp32_accuracy(hip):
     P.check_conv_b3(hip, 1, 512, 256, 16, 32, dual=256, xform=True)
 
 
+def test_conv1x1_bf16x3_kernel_has_fp32_accuracy(hip):
+    P.check_conv_b3(hip, 1, 32, 128, 9, 33, ks=1)
+    P.check_conv_b3(hip, 2, 96, 256, 5, 40, ks=1, xform=True)
+    P.check_conv_b3(hip, 1, 160, 128, 16, 20, ks=1, dual=64)
+    P.check_conv_b3(hip, 1, 16, 128, 1, 1, ks=1)
+    P.check_conv_b3(hip, 2, 256, 128, 128, 256, ks=1, dual=128)
+    P.check_conv_b3(hip, 1, 512, 256, 64, 64, ks=1, dual=256)
+    P.check_conv_b3(hip, 1, 256, 768, 16, 32, ks=1, xform=True)
+
+
 def test_conv3x3_fp16x2_kernel_is_within_one_bit_of_fp32(hip):
     P.check_conv_b3(hip, 1, 32, 128, 9, 33, xform=True, split="fp16x2", slack=3.0)
     P.check_conv_b3(hip, 2, 48, 128, 8, 32, xform=True, split="fp16x2", slack=3.0)
