@@ -495,7 +495,8 @@ class Engine {
     a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
     if (force_direct == 2 || force_direct == 3) {          // the split kernels: 2 bf16x3, 3 fp16x2
-      SG_REQUIRE(conv_b3_eligible(ks, a.C1, C2, Cout), "op_conv2d: shape is not eligible for the split kernels");
+      SG_REQUIRE(conv_b3_eligible(ks, a.C1, C2, Cout) || conv_thin_split_eligible(ks, a.C1, C2, Cout),
+                 "op_conv2d: shape is not eligible for the split kernels");
       const float* pk = pack_split(w_oihw, ks, Cin, Cout, force_direct - 1, false, &a.acc_scale);
       a.w = pk;
       launch_conv_split(a, ks, force_direct - 1, stream_);
@@ -719,7 +720,7 @@ class Engine {
       }
     }
     // 3x3: the engine's split mode; 1x1 (raw residual-stream inputs of unknown range): always the range-free bf16x3
-    if (split_mode_ && conv_b3_eligible(ks, cin, 0, cout)) {
+    if (split_mode_ && (conv_b3_eligible(ks, cin, 0, cout) || conv_thin_split_eligible(ks, cin, 0, cout))) {
       c.split_mode = ks == 3 ? split_mode_ : 1;
       c.packed_split = pack_split(c.oihw, ks, cin, cout, c.split_mode, true, &c.split_scale);
     }
@@ -953,7 +954,8 @@ class Engine {
     }
     // fp32-accurate bf16x3 kernel for the wide levels.  Decided per layer and per IMAGE (never by the batch size), because
     // its results differ from the fp32-MFMA kernels in the last bits and an utterance must not depend on its batch.
-    const bool use_b3 = use_mfma && w.packed_split && conv_b3_eligible(w.ks, a.C, b ? b->C : 0, w.cout) &&
+    const bool use_b3 = use_mfma && w.packed_split &&
+                        (conv_b3_eligible(w.ks, a.C, b ? b->C : 0, w.cout) || conv_thin_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout)) &&
                         (long)((a.H + 7) / 8) * ((a.W + 31) / 32) >= b3_min_tiles_ &&
                         (w.split_mode != 2 || xf.scale != nullptr || xf.bounded);   // fp16x2 presumes the O(1) output of a GroupNorm producer
     if (emit_stats && use_mfma && fuse_gn_stats_) {
@@ -975,7 +977,7 @@ class Engine {
       launch_conv_split(ca, w.ks, w.split_mode, stream_);
       if (prof_ && prof_dump_)
         snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "");
-      tick(w.ks == 3 ? TC_CONV3_BIG : TC_CONV1, fl);
+      tick(w.ks == 3 ? (w.cout >= 128 ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else if (use_mfma) {
       ConvPlan pl{co_t, rows_, true};
       ca.w = (co_t == w.co_t) ? w.packed : w.packed32;

@@ -148,12 +148,19 @@ inline size_t packed_split_frags(int cin, int cout, int taps = 9) { return (size
 template <class S>
 inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<S>(cin, cout) * 16 + 16; }
 
-template <class S>
+// THIN = false: the four waves own the four 32-channel fragments of a 128-channel block, each all 8 pixel fragments.
+// THIN = true (Cout <= 32, the C->4 pyramid convolutions): one 32-channel fragment (zero-padded weights), the four waves
+// own two pixel fragments each -- 1/4 of the MFMA work of a full block for the same staged tile; these layers are bound
+// by the producer arithmetic and HBM, not by the matrix pipe.
+template <class S, bool THIN = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   using C = ConvSplitGeom;
-  using T = ConvTile<3, 4, 1, 8, 1>;       // epilogue geometry: 4 channel-waves x 1 fragment, 8 pixel fragments
-  static_assert(T::CO_T == 128 && T::ROWS == 8, "tile");
+  // epilogue geometry: 4 channel-waves x 1 fragment x 8 pixel fragments, or 1 channel-wave, 4 pixel-waves x 2 fragments
+  using T = std::conditional_t<THIN, ConvTile<3, 1, 1, 2, 1>, ConvTile<3, 4, 1, 8, 1>>;
+  static_assert(T::CO_T == (THIN ? 32 : 128) && T::ROWS == 8, "tile");
   constexpr int NS = S::NS, PX_V = S::PX_V;
+  constexpr int FPW = THIN ? 2 : 8;        // pixel fragments per wave
+  constexpr int EPJ = 8 / FPW;             // producer elements staged behind each fragment's MFMAs
   constexpr int STAGE_V = C::TROWS * C::TCOLS * PX_V;
   __shared__ u32x4 s_in0[STAGE_V];
   __shared__ u32x4 s_in1[STAGE_V];
@@ -254,24 +261,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     for (int s = 0; s < NS; ++s) sbuf[it_loff[i] + s] = pk[s];
   };
 
-  f32x16 acc[1][8];
+  f32x16 acc[1][FPW];
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < FPW; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
 
   const int nst = Cin / C::KC;
-  // A fragments of this wave: [co_blk][stage][tap][split][wave][lane]
-  const u32x4* wbase = reinterpret_cast<const u32x4*>(p.w) + (size_t)co_blk * nst * 9 * NS * 4 * 64 + wave * 64 + lane;
+  // A fragments of this wave: [co_blk][stage][tap][split][wave][lane] (THIN: every wave uses fragment 0)
+  const u32x4* wbase = reinterpret_cast<const u32x4*>(p.w) + (size_t)co_blk * nst * 9 * NS * 4 * 64 + (THIN ? 0 : wave) * 64 + lane;
   auto load_a = [&](int st, int tap, u32x4 (&a)[NS]) {
     const u32x4* q = wbase + ((size_t)st * 9 + tap) * NS * 4 * 64;
 #pragma unroll
     for (int s = 0; s < NS; ++s) a[s] = q[s * 4 * 64];
   };
   // B fragment base of this lane inside a stage buffer (u32x4 units): pixel (row j + dy, col l31 + dx), k-group kg
-  const int b_lane = l31 * PX_V + kg * NS;
+  const int b_lane = l31 * PX_V + kg * NS + (THIN ? wave * FPW * C::TCOLS * PX_V : 0);
 
-  // one tap of one stage: 8 pixel fragments x NP split products.  The B reads of fragment j+1 are issued before the
+  // one tap of one stage: FPW pixel fragments x NP split products.  The B reads of fragment j+1 are issued before the
   // MFMAs of fragment j (order pinned with sched_barrier: left alone, the compiler sinks every LDS read to just in front
   // of its first use and waits lgkmcnt(0) for each).
   auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[NS], int item, int c0n, u32x4* nxt) {
@@ -281,8 +288,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) bq[0][s] = sb[s];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j + 1 < 8) {
+    for (int j = 0; j < FPW; ++j) {
+      if (j + 1 < FPW) {
         const u32x4* q = sb + (j + 1) * C::TCOLS * PX_V;
 #pragma unroll
         for (int s = 0; s < NS; ++s) bq[(j + 1) & 1][s] = q[s];
@@ -293,8 +300,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       for (int k = 0; k < S::NP; ++k) c = S::mfma(a[S::pa(k)], bq[j & 1][S::pb(k)], c);
       acc[0][j] = c;
       if (item >= 0) {
-        stage_elem(item, j, c0n);
-        if (j == 7) flush_item(item, nxt);
+#pragma unroll
+        for (int e = 0; e < EPJ; ++e) stage_elem(item, j * EPJ + e, c0n);
+        if (j == FPW - 1) flush_item(item, nxt);
       }
       __builtin_amdgcn_sched_barrier(SGMSE_SPLIT_FENCE);
     }
@@ -336,7 +344,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     for (int s = 0; s < NS; ++s) a0[s] = a1[s];
   }
 
-  conv_epilogue<T, 1, 8, 4>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);
+  if constexpr (THIN) conv_epilogue<T, 1, FPW, 1>(p, acc, b, co_blk, tx, ty, tiles_x, 0, wave, l31, kg);
+  else conv_epilogue<T, 1, 8, 4>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -60,6 +60,13 @@ def test_conv3x3_bf16x3_kernel_has_fp32_accuracy(emu):
     P.check_conv_b3(emu, 1, 64, 256, 5, 40, dual=32, xform=True)
 
 
+def test_conv3x3_thin_output_split_kernel(emu):
+    """C -> 4 pyramid convolutions on the split kernel's thin variant (one padded 32-channel fragment, waves split pixels)."""
+    P.check_conv_b3(emu, 1, 64, 4, 9, 33, xform=True, split="fp16x2", slack=3.0)
+    P.check_conv_b3(emu, 2, 128, 4, 8, 40, xform=True, split="fp16x2", slack=3.0)
+    P.check_conv_b3(emu, 1, 64, 4, 5, 32, xform=True, split="bf16x3")
+
+
 def test_conv1x1_bf16x3_kernel_has_fp32_accuracy(emu):
     P.check_conv_b3(emu, 1, 32, 128, 9, 33, ks=1)
     P.check_conv_b3(emu, 2, 96, 256, 5, 40, ks=1, xform=True)

@@ -66,6 +66,15 @@ def test_conv3x3_bf16x3_kernel_has_fp32_accuracy(hip):
     P.check_conv_b3(hip, 1, 512, 256, 16, 32, dual=256, xform=True)
 
 
+def test_conv3x3_thin_output_split_kernel(hip):
+    """C -> 4 pyramid convolutions on the split kernel's thin variant (one padded 32-channel fragment, waves split pixels)."""
+    P.check_conv_b3(hip, 1, 64, 4, 9, 33, xform=True, split="fp16x2", slack=3.0)
+    P.check_conv_b3(hip, 2, 128, 4, 8, 40, xform=True, split="fp16x2", slack=3.0)
+    P.check_conv_b3(hip, 1, 64, 4, 5, 32, xform=True, split="bf16x3")
+    P.check_conv_b3(hip, 2, 128, 4, 128, 256, xform=True, split="fp16x2", slack=3.0)
+    P.check_conv_b3(hip, 1, 256, 4, 64, 128, xform=True, split="fp16x2", slack=3.0)
+
+
 def test_conv1x1_bf16x3_kernel_has_fp32_accuracy(hip):
     P.check_conv_b3(hip, 1, 32, 128, 9, 33, ks=1)
     P.check_conv_b3(hip, 2, 96, 256, 5, 40, ks=1, xform=True)
