@@ -10,7 +10,7 @@ rank enhances its own batch (weak scaling), the only collective is one weight br
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     dominant kernel = the 3x3 convolution of the wide U-Net levels (128-channel x 256-pixel tile): by default
                the fp16x2 split kernel (fp32 operands as two fp16 terms, three partial products on the f16 MFMA pipe, fp32
-               accumulate; kernels_conv_b3.h).  achieved = ALGORITHMIC fp32 FLOPs of its launches / their HIP-event time,
+               accumulate; kernels_conv_split.h).  achieved = ALGORITHMIC fp32 FLOPs of its launches / their HIP-event time,
                measured by one instrumented (eager) network evaluation on the same batch right after the timed region;
                peak = the dense MFMA peak of the instruction used divided by the partial products per algorithmic
                multiply: 2500/3 (fp16x2), 2500/6 (bf16x3), 157.3 (fp32 MFMA) TFLOP/s (MI355X_MICROARCH.md)
@@ -237,7 +237,7 @@ def main():
             tt = torch.full((a.batch,), 0.5, device=dev)
             ctx = model.dnn.engine(dev)
             prof, _ = ctx.profile_forward(Y, tt)
-            dom = prof["conv3x3_mfma_128x256"]
+            dom = prof["conv3x3_wide"]
             ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
             kname, peak, peak_note, prefix = DOMINANT[ctx.conv_split_mode()]
             traffic, traffic_note = hbm_traffic_of_dominant_kernel(prefix)

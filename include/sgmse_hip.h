@@ -144,7 +144,7 @@ int sgmse_op_fir(sgmse_ctx* ctx, const float* x, float* out, int BC, int H, int 
 int sgmse_op_attention(sgmse_ctx* ctx, const float* qkv, float* out, int B, int C, int S);
 
 /* which kernel family the wide 3x3 layers use in this context: 0 fp32 MFMA, 1 bf16x3 split, 2 fp16x2 split
- * (SGMSE_CONV_SPLIT, read at configure time; kernels_conv_b3.h) */
+ * (SGMSE_CONV_SPLIT, read at configure time; kernels_conv_split.h) */
 int sgmse_conv_split_mode(sgmse_ctx* ctx, int* out);
 
 /* -- measurement: one eager forward with HIP events (on the context's stream) around every kernel launch, summed per

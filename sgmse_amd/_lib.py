@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libsgmse_hip.so")
 
 SGMSE_NCLASS = 8
-CLASS_NAMES = ("conv3x3_mfma_128x256", "conv3x3_mfma_other", "conv1x1_mfma", "conv_direct", "groupnorm_stats", "fir",
+CLASS_NAMES = ("conv3x3_wide", "conv3x3_other", "conv1x1", "conv_direct", "groupnorm_stats", "fir",
                "attention", "entry_exit")
 CLASS_WORK_UNIT = ("flop", "flop", "flop", "flop", "byte", "byte", "flop", "byte")
 
@@ -358,7 +358,7 @@ class Context:
         return ms.value
 
     def conv_split_mode(self) -> int:
-        """0: fp32 MFMA, 1: bf16x3 split, 2: fp16x2 split on the wide 3x3 layers (kernels_conv_b3.h)."""
+        """0: fp32 MFMA, 1: bf16x3 split, 2: fp16x2 split on the wide 3x3 layers (kernels_conv_split.h)."""
         out = C.c_int(0)
         self.check(self.lib.sgmse_conv_split_mode(self.h, C.byref(out)))
         return out.value

@@ -3,7 +3,7 @@
 #include "kernels_conv.h"
 #include "kernels_conv_pipe.h"
 #include "kernels_conv1x1.h"
-#include "kernels_conv_b3.h"
+#include "kernels_conv_split.h"
 
 #ifndef SGMSE_CONV_SPLIT_DEFAULT
 #define SGMSE_CONV_SPLIT_DEFAULT 2     // 0: fp32 MFMA everywhere, 1: bf16x3 on the wide levels, 2: fp16x2 on the wide levels
@@ -76,8 +76,8 @@ inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt:
 #undef SGMSE_CONV_CASE
 }
 
-// bf16x3 3x3 convolution (kernels_conv_b3.h); a.w = weights packed by pack_weights_b3_kernel
-inline bool conv_b3_eligible(int ks, int C1, int C2, int Cout) {
+// split-operand convolutions (kernels_conv_split.h); a.w = weights packed by pack_weights_split_kernel
+inline bool conv_split_eligible(int ks, int C1, int C2, int Cout) {
   return (ks == 3 || ks == 1) && Cout % 128 == 0 && (C1 + C2) % 16 == 0 && (C2 == 0 || C1 % 16 == 0) && (C1 + C2) <= 512;
 }
 // thin 3x3 layers (the C->4 pyramid convolutions): one zero-padded 32-channel fragment, the waves split the pixels

@@ -232,7 +232,7 @@ struct ConvW {            // one convolution's parameters on the device
   const float* packed = nullptr; // MFMA layout (null if the shape is not MFMA-eligible)
   const float* packed32 = nullptr; // second MFMA layout with 32-channel output tiles: 4x more workgroups for launches that
                                    // would otherwise leave most CUs idle (the 16x32 ... 4x8 levels of the U-Net)
-  const float* packed_split = nullptr; // split-kernel fragment layout (kernels_conv_b3.h) in the engine's split mode,
+  const float* packed_split = nullptr; // split-kernel fragment layout (kernels_conv_split.h) in the engine's split mode,
                                        // 3x3 with cout % 128 == 0, cin % 16 == 0
   const float* split_scale = nullptr;  // fp16x2: device scalar 2^-(k+4) behind the packed fragments
   int split_mode = 0;                  // 1 bf16x3, 2 fp16x2 (0: no split layout)
@@ -495,7 +495,7 @@ class Engine {
     a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
     if (force_direct == 2 || force_direct == 3) {          // the split kernels: 2 bf16x3, 3 fp16x2
-      SG_REQUIRE(conv_b3_eligible(ks, a.C1, C2, Cout) || conv_thin_split_eligible(ks, a.C1, C2, Cout),
+      SG_REQUIRE(conv_split_eligible(ks, a.C1, C2, Cout) || conv_thin_split_eligible(ks, a.C1, C2, Cout),
                  "op_conv2d: shape is not eligible for the split kernels");
       const float* pk = pack_split(w_oihw, ks, Cin, Cout, force_direct - 1, false, &a.acc_scale);
       a.w = pk;
@@ -596,7 +596,7 @@ class Engine {
     if (variant >= 0) { ablate = (variant >> 12) & 15; variant &= 4095; }       // measurement knob: ablation bits 12..15
     const int smode = variant < 0 ? 0 : ((variant & 128) ? 2 : ((variant & 64) ? 1 : 0));
     const bool b3 = smode != 0;
-    SG_REQUIRE(!b3 || conv_b3_eligible(ks, Cin, 0, Cout), "bench_conv: shape is not eligible for the split kernels");
+    SG_REQUIRE(!b3 || conv_split_eligible(ks, Cin, 0, Cout), "bench_conv: shape is not eligible for the split kernels");
     const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * Cout * H * W, nw = (size_t)Cout * Cin * ks * ks;
     const size_t ne = packed_weight_elems(ks, Cin, Cout, pl.co_t);
     float* x = static_cast<float*>(dev_alloc_tmp(nx * 4));
@@ -720,7 +720,7 @@ class Engine {
       }
     }
     // 3x3: the engine's split mode; 1x1 (raw residual-stream inputs of unknown range): always the range-free bf16x3
-    if (split_mode_ && (conv_b3_eligible(ks, cin, 0, cout) || conv_thin_split_eligible(ks, cin, 0, cout))) {
+    if (split_mode_ && (conv_split_eligible(ks, cin, 0, cout) || conv_thin_split_eligible(ks, cin, 0, cout))) {
       c.split_mode = ks == 3 ? split_mode_ : 1;
       c.packed_split = pack_split(c.oihw, ks, cin, cout, c.split_mode, true, &c.split_scale);
     }
@@ -772,7 +772,7 @@ class Engine {
       DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, pa);
       c.packed = pk;
     }
-    if (split_mode_ && conv_b3_eligible(1, C, 0, c.cout)) {
+    if (split_mode_ && conv_split_eligible(1, C, 0, c.cout)) {
       c.split_mode = 1;
       c.packed_split = pack_split(c.oihw, 1, C, c.cout, 1, true, &c.split_scale);
     }
@@ -954,9 +954,9 @@ class Engine {
     }
     // fp32-accurate bf16x3 kernel for the wide levels.  Decided per layer and per IMAGE (never by the batch size), because
     // its results differ from the fp32-MFMA kernels in the last bits and an utterance must not depend on its batch.
-    const bool use_b3 = use_mfma && w.packed_split &&
-                        (conv_b3_eligible(w.ks, a.C, b ? b->C : 0, w.cout) || conv_thin_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout)) &&
-                        (long)((a.H + 7) / 8) * ((a.W + 31) / 32) >= b3_min_tiles_ &&
+    const bool use_split = use_mfma && w.packed_split &&
+                        (conv_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout) || conv_thin_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout)) &&
+                        (long)((a.H + 7) / 8) * ((a.W + 31) / 32) >= split_min_tiles_ &&
                         (w.split_mode != 2 || xf.scale != nullptr || xf.bounded);   // fp16x2 presumes the O(1) output of a GroupNorm producer
     if (emit_stats && use_mfma && fuse_gn_stats_) {
       o.nsub = conv_plan_nsub(a.H, a.W);
@@ -972,7 +972,7 @@ class Engine {
     ca.res = res; ca.out_scale = out_scale; ca.out = o.p; ca.Cout = w.cout; ca.B = B_; ca.H = a.H; ca.W = a.W;
     tock();
     const double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
-    if (use_b3) {
+    if (use_split) {
       ca.w = w.packed_split; ca.acc_scale = w.split_scale;
       launch_conv_split(ca, w.ks, w.split_mode, stream_);
       if (prof_ && prof_dump_)
@@ -985,7 +985,8 @@ class Engine {
       if (prof_ && prof_dump_)
         snprintf(prof_note_, sizeof prof_note_, "conv%dx%d %d->%d @%dx%dx%d tile %dco x %drows%s%s", w.ks, w.ks, Cin, w.cout, B_, a.H, a.W,
                  co_t, rows_, res ? " +res" : "", xf.scale ? " +gn" : "");
-      tick(w.ks == 3 ? ((co_t == 128 && pl.rows == 8) ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
+      // class "wide" = the dominant kernel family only: the split kernels, or (SGMSE_CONV_SPLIT=0) the fp32 128 x 256 tile
+      tick(w.ks == 3 ? ((split_mode_ == 0 && co_t == 128 && pl.rows == 8) ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else {
       ca.w = w.oihw;
       launch_conv_direct(ca, w.ks, stream_);
@@ -1225,11 +1226,11 @@ class Engine {
     e = getenv("SGMSE_CONV_SPLIT");                      // 0: fp32 MFMA only, 1: bf16x3, 2: fp16x2 on the wide levels
     split_mode_ = e ? atoi(e) : SGMSE_CONV_SPLIT_DEFAULT;
     SG_REQUIRE(split_mode_ >= 0 && split_mode_ <= 2, "SGMSE_CONV_SPLIT must be 0, 1 or 2");
-    e = getenv("SGMSE_B3_MIN_TILES");
-    b3_min_tiles_ = e ? atol(e) : 8L;                    // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
+    e = getenv("SGMSE_SPLIT_MIN_TILES");
+    split_min_tiles_ = e ? atol(e) : 8L;                    // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
   }
-  long tile_min_blocks_ = 512, b3_min_tiles_ = 8;
+  long tile_min_blocks_ = 512, split_min_tiles_ = 8;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};

@@ -194,18 +194,23 @@ def check_tile_independence(dev, name, batch=None):
     assert rel_l2(outs[0], torch.from_numpy(z["out"])[:len(x)]) < NET_TOL
 
 
-def check_forward_b3_everywhere(dev, name="fwd_nf128"):
-    """Network-level parity with the bf16x3 kernel on EVERY eligible 3x3 layer (SGMSE_B3_MIN_TILES=1; by default only the
-    wide levels use it), against the reference's own output, at the same gate as the fp32 kernels."""
-    old = os.environ.get("SGMSE_B3_MIN_TILES")
-    os.environ["SGMSE_B3_MIN_TILES"] = "1"
+def check_forward_b3_everywhere(dev, name="fwd_nf128", mode=None):
+    """Network-level parity with a split kernel on EVERY eligible layer (SGMSE_SPLIT_MIN_TILES=1; by default only layers
+    with >= 8 tiles per image use one), against the reference's own output, at the same gate as the fp32 kernels.
+    mode: None = the build default (fp16x2), 1 = bf16x3, 0 = exact-fp32 MFMA kernels everywhere."""
+    keys = {"SGMSE_SPLIT_MIN_TILES": "1"}
+    if mode is not None:
+        keys["SGMSE_CONV_SPLIT"] = str(mode)
+    old = {k: os.environ.get(k) for k in keys}
+    os.environ.update(keys)
     try:
         check_forward_golden(dev, name)
     finally:
-        if old is None:
-            os.environ.pop("SGMSE_B3_MIN_TILES", None)
-        else:
-            os.environ["SGMSE_B3_MIN_TILES"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def make_model(cfg, dev, P=None, sde="ouve", **kw):

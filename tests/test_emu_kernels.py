@@ -148,8 +148,9 @@ def test_forward_matches_reference_ncsnpp_48k(emu):
 @pytest.mark.skipif(not SLOW, reason="full-width network on the emulator takes minutes; SGMSE_SLOW=1")
 @pytest.mark.slow
 @pytest.mark.skipif(not os.environ.get("SGMSE_SLOW"), reason="full-width network on the emulator (minutes); set SGMSE_SLOW=1")
-def test_forward_with_bf16x3_on_every_eligible_layer(emu):
-    P.check_forward_b3_everywhere(emu)
+@pytest.mark.parametrize("mode", [None, 1])
+def test_forward_with_split_kernels_on_every_eligible_layer(emu, mode):
+    P.check_forward_b3_everywhere(emu, mode=mode)
 
 
 @pytest.mark.slow

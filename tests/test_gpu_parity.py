@@ -94,8 +94,10 @@ def test_conv3x3_fp16x2_kernel_is_within_one_bit_of_fp32(hip):
     P.check_conv_b3(hip, 1, 512, 256, 16, 32, dual=256, xform=True, split="fp16x2", slack=3.0)
 
 
-def test_forward_with_bf16x3_on_every_eligible_layer(hip):
-    P.check_forward_b3_everywhere(hip)
+@pytest.mark.parametrize("mode", [None, 1, 0])
+def test_forward_with_split_kernels_on_every_eligible_layer(hip, mode):
+    """fp16x2 (default), bf16x3 and exact-fp32 kernel families all meet the network-level gate."""
+    P.check_forward_b3_everywhere(hip, mode=mode)
 
 
 def test_conv1x1_wide_output(hip):
