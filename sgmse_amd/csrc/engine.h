@@ -160,6 +160,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs p) {
 }
 
 // deterministic pseudo-random fill in [-1, 1) (benchmark operands must not be zeros: DVFS, MI355X_MICROARCH.md)
+__global__ __launch_bounds__(256) void zero_floats_kernel(float* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void fill_random_kernel(float* dst, size_t n, uint32_t seed) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -225,7 +230,8 @@ class Arena {
   std::map<size_t, size_t> live_;
 };
 
-struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; float* st = nullptr; int nsub = 0; };   // st: [B][C][nsub][2] GroupNorm partial sums
+// st: [B][C][nsub][2] GroupNorm partial sums; amax: [B] upper bounds of |x| per utterance (null: unknown range)
+struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; float* st = nullptr; int nsub = 0; float* amax = nullptr; };
 
 struct ConvW {            // one convolution's parameters on the device
   const float* oihw = nullptr;   // [cout][cin][ks][ks] (for NIN: transposed copy)
@@ -487,6 +493,21 @@ class Engine {
   size_t arena_bytes() const { return arena_cap_; }
 
   // ---- single ops (op-level C ABI + tests) ------------------------------------------------------------------
+  // per-utterance max |x| of one or two NCHW tensors -> [B] (+ [B]) floats, for the op-level entry points
+  float* input_bounds(const float* x1, int C1, const float* x2, int C2, int B, int HW) {
+    float* out = static_cast<float*>(dev_alloc_tmp((size_t)2 * B * 4));
+    SG_CHECK(drt::memset_dev(out, 0, (size_t)2 * B * 4, stream_));
+    for (int b = 0; b < B; ++b) {
+      const size_t n1 = (size_t)C1 * HW;
+      DRT_LAUNCH(absmax_kernel, dim3((unsigned)std::min<size_t>((n1 + 255) / 256, 1024)), dim3(256), stream_, x1 + b * n1, n1, out + b);
+      if (x2) {
+        const size_t n2 = (size_t)C2 * HW;
+        DRT_LAUNCH(absmax_kernel, dim3((unsigned)std::min<size_t>((n2 + 255) / 256, 1024)), dim3(256), stream_, x2 + b * n2, n2, out + B + b);
+      }
+    }
+    return out;
+  }
+
   void op_conv2d(const float* x, const float* w_oihw, const float* bias, const float* res, float* out, int B, int Cin,
                  int Cout, int H, int W, int ks, float out_scale, int force_direct, const float* in_scale,
                  const float* in_shift, int in_act, const float* x2, int C2) {
@@ -497,11 +518,19 @@ class Engine {
     if (force_direct == 2 || force_direct == 3) {          // the split kernels: 2 bf16x3, 3 fp16x2
       SG_REQUIRE(conv_split_eligible(ks, a.C1, C2, Cout) || conv_thin_split_eligible(ks, a.C1, C2, Cout),
                  "op_conv2d: shape is not eligible for the split kernels");
-      const float* pk = pack_split(w_oihw, ks, Cin, Cout, force_direct - 1, false, &a.acc_scale);
+      const int smode = force_direct - 1;
+      const float* pk = pack_split(w_oihw, ks, Cin, Cout, smode, false, &a.acc_scale, ks == 3 ? kH2XScale : 1.f);
       a.w = pk;
-      launch_conv_split(a, ks, force_direct - 1, stream_);
+      float* bounds = nullptr;
+      if (ks == 1 && smode == 2) {      // dynamic input scale: range bounds as a producer would have left them
+        SG_REQUIRE(in_scale == nullptr, "op_conv2d: the fp16x2 1x1 kernel takes raw inputs (no fused producer)");
+        bounds = input_bounds(x, a.C1, x2, C2, B, H * W);
+        a.amax1 = bounds; a.amax2 = x2 ? bounds + B : nullptr;
+      }
+      launch_conv_split(a, ks, smode, stream_);
       SG_CHECK(drt::stream_sync(stream_));
       free_tmp(const_cast<float*>(pk));
+      if (bounds) free_tmp(bounds);
     } else if (pl.mfma && !force_direct && (C2 == 0 || a.C1 % ((ks == 3) ? 8 : 32) == 0)) {
       const size_t ne = packed_weight_elems(ks, Cin, Cout, pl.co_t);
       float* pk = static_cast<float*>(dev_alloc_tmp(ne * 4));
@@ -619,7 +648,15 @@ class Engine {
     drt::event_t e0{}, e1{};
     drt::event_create(&e0); drt::event_create(&e1);
     const float* pk3 = nullptr;
-    if (b3) { pk3 = pack_split(w, ks, Cin, Cout, smode, false, &a.acc_scale); a.w = pk3; }
+    float* bounds = nullptr;
+    if (b3) {
+      pk3 = pack_split(w, ks, Cin, Cout, smode, false, &a.acc_scale, ks == 3 ? kH2XScale : 1.f); a.w = pk3;
+      if (ks == 1 && smode == 2) {
+        a.in_scale = nullptr; a.in_shift = nullptr; a.in_act = 0;       // raw input, as in the network's shortcut layers
+        bounds = input_bounds(x, Cin, nullptr, 0, B, H * W);
+        a.amax1 = bounds;
+      }
+    }
     auto go = [&]() { if (b3) launch_conv_split(a, ks, smode, stream_); else launch_conv_mfma(a, ks, pl, stream_, variant); };
     for (int i = 0; i < 2; ++i) go();
     drt::event_record(&e0, stream_);
@@ -631,6 +668,7 @@ class Engine {
     drt::event_destroy(&e0); drt::event_destroy(&e1);
     for (float* q : {x, o, r, w, pk, sc}) free_tmp(q);
     if (pk3) free_tmp(const_cast<float*>(pk3));
+    if (bounds) free_tmp(bounds);
     return ms;
   }
 
@@ -719,21 +757,23 @@ class Engine {
         c.packed32 = pk32;
       }
     }
-    // 3x3: the engine's split mode; 1x1 (raw residual-stream inputs of unknown range): always the range-free bf16x3
+    // fp16x2: 3x3 layers scale their (GroupNorm-produced) input by a fixed 2^4, 1x1 layers (raw residual stream) by a
+    // power of two derived at run time from the producers' range bounds -- the stored factor then only undoes the weights'
     if (split_mode_ && (conv_split_eligible(ks, cin, 0, cout) || conv_thin_split_eligible(ks, cin, 0, cout))) {
-      c.split_mode = ks == 3 ? split_mode_ : 1;
-      c.packed_split = pack_split(c.oihw, ks, cin, cout, c.split_mode, true, &c.split_scale);
+      c.split_mode = split_mode_;
+      c.packed_split = pack_split(c.oihw, ks, cin, cout, c.split_mode, true, &c.split_scale, ks == 3 ? kH2XScale : 1.f);
     }
     return c;
   }
 
   // weights in the fragment order of conv3x3_split_kernel (mode 1: bf16x3, 2: fp16x2 with the layer's power-of-two scale)
-  const float* pack_split(const float* oihw, int ks, int cin, int cout, int mode, bool weight_owned, const float** scale_out) {
+  const float* pack_split(const float* oihw, int ks, int cin, int cout, int mode, bool weight_owned, const float** scale_out,
+                          float xscale) {
     const int taps = ks * ks;
     const size_t frags = mode == 2 ? packed_split_frags<SplitH2>(cin, cout, taps) : packed_split_frags<SplitB3>(cin, cout, taps);
     const size_t bytes = frags * 16 + 16;
     uint32_t* pk = static_cast<uint32_t*>(weight_owned ? dev_alloc_w(bytes) : dev_alloc_tmp(bytes));
-    PackSplitArgs pa{oihw, pk, cin, cout, frags, nullptr, taps};
+    PackSplitArgs pa{oihw, pk, cin, cout, frags, nullptr, taps, xscale};
     const dim3 grid((unsigned)((frags + 255) / 256));
     if (mode == 2) {
       float* amax = reinterpret_cast<float*>(pk) + frags * 4 + 1;     // scratch word behind the scale
@@ -774,7 +814,7 @@ class Engine {
     }
     if (split_mode_ && conv_split_eligible(1, C, 0, c.cout)) {
       c.split_mode = 1;
-      c.packed_split = pack_split(c.oihw, 1, C, c.cout, 1, true, &c.split_scale);
+      c.packed_split = pack_split(c.oihw, 1, C, c.cout, 1, true, &c.split_scale, 1.f);
     }
     return c;
   }
@@ -847,6 +887,11 @@ class Engine {
       if (n > samp_n_) {
         for (float2** q : {&sx_, &sxm_, &sscore_, &sy_}) { if (*q) dev_free_owned(*q); *q = static_cast<float2*>(dev_alloc(n * 8)); }
         samp_n_ = n;
+      }
+      if (B > amax_pool_B_) {
+        if (amax_pool_) dev_free_owned(amax_pool_);
+        amax_pool_ = static_cast<float*>(dev_alloc((size_t)kAmaxSlots * B * 4));
+        amax_pool_B_ = B;
       }
       if (!step_ctr_) step_ctr_ = static_cast<int*>(dev_alloc(256));
       if (!lang_scal_) lang_scal_ = static_cast<float*>(dev_alloc(256));
@@ -957,14 +1002,19 @@ class Engine {
     const bool use_split = use_mfma && w.packed_split &&
                         (conv_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout) || conv_thin_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout)) &&
                         (long)((a.H + 7) / 8) * ((a.W + 31) / 32) >= split_min_tiles_ &&
-                        (w.split_mode != 2 || xf.scale != nullptr || xf.bounded);   // fp16x2 presumes the O(1) output of a GroupNorm producer
+                        // fp16x2: 3x3 layers presume the O(1) output of a GroupNorm producer (fixed scale); 1x1 layers read the
+                        // raw residual stream and scale by the producers' range bounds, which must then be known
+                        (w.split_mode != 2 || (w.ks == 3 ? (xf.scale != nullptr || xf.bounded)
+                                                         : (xf.scale == nullptr && a.amax && (!b || b->amax))));
     if (emit_stats && use_mfma && fuse_gn_stats_) {
       o.nsub = conv_plan_nsub(a.H, a.W);
       o.st = arena_.alloc((size_t)B_ * w.cout * o.nsub * 2);
     }
+    o.amax = next_amax();
     if (dry_) return o;
     ConvArgs ca{};
     ca.stats_out = o.st; ca.stats_nsub = o.nsub;
+    ca.amax_out = o.amax;
     ca.src1 = a.p; ca.src2 = b ? b->p : nullptr; ca.C1 = a.C; ca.C2 = b ? b->C : 0;
     ca.bias = bias; ca.bias2 = bias2; ca.bias2_bstride = ctl.bias_bstride; ca.bias2_sstride = ctl.bias_sstride;
     ca.step_ptr = bias2 ? ctl.step_ptr : nullptr;
@@ -974,6 +1024,7 @@ class Engine {
     const double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
     if (use_split) {
       ca.w = w.packed_split; ca.acc_scale = w.split_scale;
+      if (w.ks == 1 && w.split_mode == 2) { ca.amax1 = a.amax; ca.amax2 = b ? b->amax : nullptr; }
       launch_conv_split(ca, w.ks, w.split_mode, stream_);
       if (prof_ && prof_dump_)
         snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "");
@@ -1009,7 +1060,10 @@ class Engine {
   // FIR x2 / /2 of `a` through the fused producer `xf`; with `raw` also FIR(a) itself from the same pass
   Tensor fir(const Tensor& a, bool up, const Xform& xf, Tensor* raw = nullptr) {
     Tensor o = up ? new_tensor(a.C, a.H * 2, a.W * 2) : new_tensor(a.C, a.H / 2, a.W / 2);
-    if (raw) *raw = up ? new_tensor(a.C, a.H * 2, a.W * 2) : new_tensor(a.C, a.H / 2, a.W / 2);
+    if (raw) {
+      *raw = up ? new_tensor(a.C, a.H * 2, a.W * 2) : new_tensor(a.C, a.H / 2, a.W / 2);
+      raw->amax = a.amax;      // the [1,3,3,1] resamplers are convex combinations (per output phase): max|FIR(x)| <= max|x|
+    }
     if (dry_) return o;
     FirArgs fa{a.p, o.p, xf.scale, xf.shift, xf.act, B_ * a.C, a.H, a.W, raw ? raw->p : nullptr};
     tock();
@@ -1080,6 +1134,8 @@ class Engine {
   void run_forward(const float2* x, long long xbs, const float2* y, long long ybs, float2* out, int B, int F, int T,
                    const FwdCtl& ctl) {
     B_ = B;
+    amax_next_ = 0;
+    if (!dry_ && amax_pool_) DRT_LAUNCH(zero_floats_kernel, dim3((kAmaxSlots * B + 255) / 256), dim3(256), stream_, amax_pool_, kAmaxSlots * B);
     const NetCfg& c = cfg_;
     const int L = c.n_levels;
     size_t mi = 3;
@@ -1229,6 +1285,13 @@ class Engine {
     e = getenv("SGMSE_SPLIT_MIN_TILES");
     split_min_tiles_ = e ? atol(e) : 8L;                    // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
+  }
+  static constexpr int kAmaxSlots = 512;     // per-forward range-bound slots ([B] floats each), handed out in program order
+  float* amax_pool_ = nullptr; int amax_pool_B_ = 0, amax_next_ = 0;
+  float* next_amax() {
+    SG_REQUIRE(amax_next_ < kAmaxSlots, "amax pool exhausted");
+    const int i = amax_next_++;
+    return amax_pool_ ? amax_pool_ + (size_t)i * B_ : nullptr;
   }
   long tile_min_blocks_ = 512, split_min_tiles_ = 8;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;

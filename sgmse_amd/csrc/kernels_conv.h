@@ -50,6 +50,12 @@ struct ConvArgs {
   // on which tile shape a launch used.  Deterministic (no atomics); stats_nsub = H * ceil(W/32).
   float* stats_out;
   int stats_nsub;
+  // optional per-utterance max |stored output| ([B], atomic max: order-independent, so deterministic; zeroed by the engine
+  // before the forward): the range bound from which an fp16x2 consumer of this tensor picks its exact power-of-two scale
+  float* amax_out;
+  // per-utterance range bounds of src1 / src2 ([B] each, from the producers' amax_out) for a consumer that scales its
+  // input dynamically (conv1x1_split_kernel<SplitH2>); null otherwise
+  const float* amax1; const float* amax2;
   // measurement-only ablation switches for sgmse_bench_conv (results are then WRONG on purpose): bit 0 skip the
   // epilogue's global stores, bit 1 skip the residual read, bit 2 stage only the first K-stage, bit 3 skip the barriers
   int ablate;
@@ -89,12 +95,13 @@ struct ConvTile {
 // + residual, * out_scale, and (optionally) the per-(b, co, sub-tile) GroupNorm partial sums of the stored values.
 template <class T, int FC, int FP, int WC>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[FC][FP], int b, int co_blk, int tx, int ty,
-                                              int tiles_x, int wc, int wp, int l31, int kh) {
+                                              int tiles_x, int wc, int wp, int l31, int kh, float as_mul = 1.0f) {
   constexpr int CO_T = T::CO_T, ROWS = T::ROWS;
   const int H = p.H, W = p.W;
   const int x0 = tx * 32, y0 = ty * ROWS;
   const int x = x0 + l31;
-  const float as = p.acc_scale ? *p.acc_scale : 1.0f;     // exact power of two (or 1)
+  const float as = (p.acc_scale ? *p.acc_scale : 1.0f) * as_mul;     // exact powers of two (or 1)
+  float vmax = 0.f;
   const float* b2 = nullptr;
   if (p.bias2) {
     const int step = p.step_ptr ? *p.step_ptr : 0;
@@ -151,6 +158,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
           else if (v == 12345.678f) p.out[o] = v;   // keeps the value live without storing
         }
         v = ok ? v : 0.f;
+        vmax = fmaxf(vmax, fabsf(v));
         sv[r] = v;
         sq[r] = v * v;
       }
@@ -205,6 +213,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
         }
       }
     }
+  }
+  if (p.amax_out) {      // wave-uniform
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if ((threadIdx.x & 63) == 0) drt_atomic_max_nonneg(p.amax_out + b, vmax);
   }
 }
 
@@ -498,23 +511,30 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs p) {
       }
     }
   }
-  if (!inb) return;
   const float* b2 = nullptr;
   if (p.bias2) {
     const int step = p.step_ptr ? *p.step_ptr : 0;
     b2 = p.bias2 + (size_t)step * p.bias2_sstride + (size_t)b * p.bias2_bstride;
   }
+  float vmax = 0.f;
 #pragma unroll
   for (int g = 0; g < CG; ++g) {
     const int co = co0 + g;
-    if (co < p.Cout) {
+    if (inb && co < p.Cout) {
       const size_t o = (size_t)(b * p.Cout + co) * HW + pix;
       float v = acc[g];
       if (p.bias) v += p.bias[co];
       if (b2) v += b2[co];
       if (p.res) v += p.res[o];
-      p.out[o] = v * p.out_scale;
+      v *= p.out_scale;
+      p.out[o] = v;
+      vmax = fmaxf(vmax, fabsf(v));
     }
+  }
+  if (p.amax_out) {      // every lane of the wave is still here (no early return above)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if ((threadIdx.x & 63) == 0) drt_atomic_max_nonneg(p.amax_out + b, vmax);
   }
 }
 

@@ -85,7 +85,7 @@ struct ConvSplitGeom {
 // Weight packing.  src: OIHW fp32 [Cout][Cin][k][k] (taps = k*k = 9 or 1); dst: u32x4 [nCoBlk][Cin/16][taps][NS][4][64], followed (SplitH2) by
 // one float: the factor 2^-(k+4) that takes the accumulator back to the unscaled convolution.  `absmax` (device,
 // SplitH2 only) = max |w| of the layer, from absmax_kernel.  One thread per 16-byte fragment element.
-struct PackSplitArgs { const float* src; uint32_t* dst; int cin, cout; size_t total; const float* absmax; int taps; };
+struct PackSplitArgs { const float* src; uint32_t* dst; int cin, cout; size_t total; const float* absmax; int taps; float xscale; };
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t n, float* out) {   // *out zeroed by the caller
   float m = 0.f;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(PackSplitArgs p
   float wscale = 1.f;
   if (S::SCALED) {
     wscale = h2_weight_scale(*p.absmax);
-    if (e == 0) reinterpret_cast<float*>(p.dst)[p.total * 4] = 1.f / (wscale * kH2XScale);
+    if (e == 0) reinterpret_cast<float*>(p.dst)[p.total * 4] = 1.f / (wscale * p.xscale);   // xscale: the consumer's fixed input scale (1 if dynamic)
   }
   const int lane = (int)(e & 63);
   size_t r = e >> 6;
@@ -385,6 +385,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
   const float actf = (xform && p.in_act) ? 1.f : 0.f;
   const size_t HW = (size_t)H * W;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
+  // fp16x2 on a raw (residual-stream) input: exact power-of-two scale from the producers' per-utterance range bounds, so
+  // that max |x| 2^s lies in [2^13, 2^14) whatever the range of the stream is
+  float xs = 1.f;
+  if (S::SCALED) {
+    float m = p.amax1 ? p.amax1[b] : 0.f;
+    if (p.amax2) m = fmaxf(m, p.amax2[b]);
+    xs = h2_weight_scale(m);
+  }
 
   // staging items: (k-group g, row r, column c), c fastest; pixels outside the image are clamped (their outputs are
   // never stored and a 1x1 convolution does not mix pixels)
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
     float t = src[i][e] * s_sc[ch] + s_sh[ch];
     const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
     t *= actf * (sig - 1.0f) + 1.0f;
-    if (S::SCALED) t = fminf(fmaxf(t * kH2XScale, -65504.f), 65504.f);
+    if (S::SCALED) t = fminf(fmaxf(t * xs, -65504.f), 65504.f);    // the clamp cannot bind when the range bound holds
     uint32_t t16[NS];
     S::split(t, t16);
 #pragma unroll
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
       for (int e = 0; e < 8; ++e) rinA[i][e] = rinB[i][e];
   }
 
-  conv_epilogue<T, 1, 8, 4>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);
+  conv_epilogue<T, 1, 8, 4>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg, 1.0f / xs);
 }
 
 }  // namespace sgmse

@@ -35,7 +35,9 @@ def load(name):
 def check_conv(dev, B, Ci, Co, H, W, ks, direct=False, dual=0, xform=False):
     from sgmse_amd import ops
     g = gen(B * 1000 + Ci + Co + H + W)
-    x = R(g, B, Ci, H, W); w = R(g, Co, Ci, ks, ks) / math.sqrt(Ci * ks * ks); b = R(g, Co); r = R(g, B, Co, H, W)
+    x = R(g, B, Ci, H, W) * xmul; w = R(g, Co, Ci, ks, ks) / math.sqrt(Ci * ks * ks); b = R(g, Co) * xmul; r = R(g, B, Co, H, W) * xmul
+    if xmul != 1.0:
+        x[0] *= 0.01          # utterances of one batch with very different ranges: the scale is per utterance
     sc = sh = None
     xin = x
     if xform:
@@ -50,13 +52,15 @@ def check_conv(dev, B, Ci, Co, H, W, ks, direct=False, dual=0, xform=False):
     assert rel_l2(out.cpu(), ref) < OP_TOL, (B, Ci, Co, H, W, ks, direct, dual, xform)
 
 
-def check_conv_b3(dev, B, Ci, Co, H, W, dual=0, xform=False, split="bf16x3", slack=2.0, ks=3):
+def check_conv_b3(dev, B, Ci, Co, H, W, dual=0, xform=False, split="bf16x3", slack=2.0, ks=3, xmul=1.0):
     """The bf16x3 3x3 kernel: fp32 operands split exactly into three bf16 terms, six partial products on the bf16 MFMA
     pipe, fp32 accumulate.  Gate: the same per-op 1e-5 as the fp32 kernels against the fp32 oracle, AND an error against
     an fp64 convolution that is no worse than 2x the fp32 kernel's own (i.e. fp32 accuracy, not bf16 accuracy)."""
     from sgmse_amd import ops
     g = gen(B * 1000 + Ci + Co + H + W)
-    x = R(g, B, Ci, H, W); w = R(g, Co, Ci, ks, ks) / math.sqrt(Ci * ks * ks); b = R(g, Co); r = R(g, B, Co, H, W)
+    x = R(g, B, Ci, H, W) * xmul; w = R(g, Co, Ci, ks, ks) / math.sqrt(Ci * ks * ks); b = R(g, Co) * xmul; r = R(g, B, Co, H, W) * xmul
+    if xmul != 1.0:
+        x[0] *= 0.01          # utterances of one batch with very different ranges: the scale is per utterance
     sc = sh = None
     xin = x
     if xform:

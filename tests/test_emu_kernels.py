@@ -74,6 +74,15 @@ def test_conv1x1_bf16x3_kernel_has_fp32_accuracy(emu):
     P.check_conv_b3(emu, 1, 16, 128, 1, 1, ks=1)
 
 
+def test_conv1x1_fp16x2_kernel_scales_by_the_input_range(emu):
+    """1x1 layers read the raw residual stream: the fp16x2 kernel derives an exact power-of-two scale per utterance from
+    range bounds (here computed by the op entry point, in the network left behind by the producing epilogues), so inputs
+    of any magnitude -- far outside fp16's own range included -- keep fp32 accuracy."""
+    P.check_conv_b3(emu, 1, 32, 128, 9, 33, ks=1, split="fp16x2", slack=3.0)
+    P.check_conv_b3(emu, 2, 96, 256, 5, 40, ks=1, split="fp16x2", slack=3.0, xmul=1e6)
+    P.check_conv_b3(emu, 2, 160, 128, 16, 20, ks=1, dual=64, split="fp16x2", slack=3.0, xmul=1e-6)
+
+
 def test_conv3x3_fp16x2_kernel_is_within_one_bit_of_fp32(emu):
     P.check_conv_b3(emu, 1, 32, 128, 9, 33, xform=True, split="fp16x2", slack=3.0)
     P.check_conv_b3(emu, 2, 48, 128, 8, 32, xform=True, split="fp16x2", slack=3.0)

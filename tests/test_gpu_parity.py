@@ -85,6 +85,17 @@ def test_conv1x1_bf16x3_kernel_has_fp32_accuracy(hip):
     P.check_conv_b3(hip, 1, 256, 768, 16, 32, ks=1, xform=True)
 
 
+def test_conv1x1_fp16x2_kernel_scales_by_the_input_range(hip):
+    """1x1 layers read the raw residual stream: the fp16x2 kernel derives an exact power-of-two scale per utterance from
+    range bounds (here computed by the op entry point, in the network left behind by the producing epilogues), so inputs
+    of any magnitude -- far outside fp16's own range included -- keep fp32 accuracy."""
+    P.check_conv_b3(hip, 1, 32, 128, 9, 33, ks=1, split="fp16x2", slack=3.0)
+    P.check_conv_b3(hip, 2, 96, 256, 5, 40, ks=1, split="fp16x2", slack=3.0, xmul=1e6)
+    P.check_conv_b3(hip, 2, 160, 128, 16, 20, ks=1, dual=64, split="fp16x2", slack=3.0, xmul=1e-6)
+    P.check_conv_b3(hip, 2, 256, 128, 128, 256, ks=1, dual=128, split="fp16x2", slack=3.0)
+    P.check_conv_b3(hip, 1, 512, 256, 64, 64, ks=1, dual=256, split="fp16x2", slack=3.0, xmul=3e4)
+
+
 def test_conv3x3_fp16x2_kernel_is_within_one_bit_of_fp32(hip):
     P.check_conv_b3(hip, 1, 32, 128, 9, 33, xform=True, split="fp16x2", slack=3.0)
     P.check_conv_b3(hip, 2, 48, 128, 8, 32, xform=True, split="fp16x2", slack=3.0)
