@@ -495,14 +495,17 @@ class Engine {
   // ---- single ops (op-level C ABI + tests) ------------------------------------------------------------------
   // per-utterance max |x| of one or two NCHW tensors -> [B] (+ [B]) floats, for the op-level entry points
   float* input_bounds(const float* x1, int C1, const float* x2, int C2, int B, int HW) {
-    float* out = static_cast<float*>(dev_alloc_tmp((size_t)2 * B * 4));
-    SG_CHECK(drt::memset_dev(out, 0, (size_t)2 * B * 4, stream_));
+    const size_t per = (size_t)B * kAmaxSpread;
+    float* out = static_cast<float*>(dev_alloc_tmp(2 * per * 4));
+    SG_CHECK(drt::memset_dev(out, 0, 2 * per * 4, stream_));
     for (int b = 0; b < B; ++b) {
       const size_t n1 = (size_t)C1 * HW;
-      DRT_LAUNCH(absmax_kernel, dim3((unsigned)std::min<size_t>((n1 + 255) / 256, 1024)), dim3(256), stream_, x1 + b * n1, n1, out + b);
+      DRT_LAUNCH(absmax_kernel, dim3((unsigned)std::min<size_t>((n1 + 255) / 256, 1024)), dim3(256), stream_, x1 + b * n1, n1,
+                 out + (size_t)b * kAmaxSpread);
       if (x2) {
         const size_t n2 = (size_t)C2 * HW;
-        DRT_LAUNCH(absmax_kernel, dim3((unsigned)std::min<size_t>((n2 + 255) / 256, 1024)), dim3(256), stream_, x2 + b * n2, n2, out + B + b);
+        DRT_LAUNCH(absmax_kernel, dim3((unsigned)std::min<size_t>((n2 + 255) / 256, 1024)), dim3(256), stream_, x2 + b * n2, n2,
+                   out + per + (size_t)b * kAmaxSpread);
       }
     }
     return out;
@@ -525,7 +528,7 @@ class Engine {
       if (ks == 1 && smode == 2) {      // dynamic input scale: range bounds as a producer would have left them
         SG_REQUIRE(in_scale == nullptr, "op_conv2d: the fp16x2 1x1 kernel takes raw inputs (no fused producer)");
         bounds = input_bounds(x, a.C1, x2, C2, B, H * W);
-        a.amax1 = bounds; a.amax2 = x2 ? bounds + B : nullptr;
+        a.amax1 = bounds; a.amax2 = x2 ? bounds + (size_t)B * kAmaxSpread : nullptr;
       }
       launch_conv_split(a, ks, smode, stream_);
       SG_CHECK(drt::stream_sync(stream_));
@@ -890,7 +893,7 @@ class Engine {
       }
       if (B > amax_pool_B_) {
         if (amax_pool_) dev_free_owned(amax_pool_);
-        amax_pool_ = static_cast<float*>(dev_alloc((size_t)kAmaxSlots * B * 4));
+        amax_pool_ = static_cast<float*>(dev_alloc((size_t)kAmaxSlots * B * kAmaxSpread * 4));
         amax_pool_B_ = B;
       }
       if (!step_ctr_) step_ctr_ = static_cast<int*>(dev_alloc(256));
@@ -1135,7 +1138,10 @@ class Engine {
                    const FwdCtl& ctl) {
     B_ = B;
     amax_next_ = 0;
-    if (!dry_ && amax_pool_) DRT_LAUNCH(zero_floats_kernel, dim3((kAmaxSlots * B + 255) / 256), dim3(256), stream_, amax_pool_, kAmaxSlots * B);
+    if (!dry_ && amax_pool_) {
+      const int n = kAmaxSlots * B * kAmaxSpread;
+      DRT_LAUNCH(zero_floats_kernel, dim3((n + 255) / 256), dim3(256), stream_, amax_pool_, n);
+    }
     const NetCfg& c = cfg_;
     const int L = c.n_levels;
     size_t mi = 3;
@@ -1286,12 +1292,12 @@ class Engine {
     split_min_tiles_ = e ? atol(e) : 8L;                    // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
   }
-  static constexpr int kAmaxSlots = 512;     // per-forward range-bound slots ([B] floats each), handed out in program order
+  static constexpr int kAmaxSlots = 256;     // per-forward range-bound slots ([B][kAmaxSpread] floats each), handed out in program order
   float* amax_pool_ = nullptr; int amax_pool_B_ = 0, amax_next_ = 0;
   float* next_amax() {
     SG_REQUIRE(amax_next_ < kAmaxSlots, "amax pool exhausted");
     const int i = amax_next_++;
-    return amax_pool_ ? amax_pool_ + (size_t)i * B_ : nullptr;
+    return amax_pool_ ? amax_pool_ + (size_t)i * B_ * kAmaxSpread : nullptr;
   }
   long tile_min_blocks_ = 512, split_min_tiles_ = 8;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;

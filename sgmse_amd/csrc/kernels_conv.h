@@ -50,16 +50,28 @@ struct ConvArgs {
   // on which tile shape a launch used.  Deterministic (no atomics); stats_nsub = H * ceil(W/32).
   float* stats_out;
   int stats_nsub;
-  // optional per-utterance max |stored output| ([B], atomic max: order-independent, so deterministic; zeroed by the engine
-  // before the forward): the range bound from which an fp16x2 consumer of this tensor picks its exact power-of-two scale
+  // optional per-utterance max |stored output| ([B][kAmaxSpread]: atomic max, order-independent and therefore
+  // deterministic, spread over kAmaxSpread words per utterance so that the atomics of a launch do not serialise on one
+  // address; zeroed by the engine before the forward): the range bound from which an fp16x2 consumer of this tensor picks
+  // its exact power-of-two scale
   float* amax_out;
-  // per-utterance range bounds of src1 / src2 ([B] each, from the producers' amax_out) for a consumer that scales its
-  // input dynamically (conv1x1_split_kernel<SplitH2>); null otherwise
+  // per-utterance range bounds of src1 / src2 ([B][kAmaxSpread] each, from the producers' amax_out) for a consumer that
+  // scales its input dynamically (conv1x1_split_kernel<SplitH2>); null otherwise
   const float* amax1; const float* amax2;
   // measurement-only ablation switches for sgmse_bench_conv (results are then WRONG on purpose): bit 0 skip the
   // epilogue's global stores, bit 1 skip the residual read, bit 2 stage only the first K-stage, bit 3 skip the barriers
   int ablate;
 };
+
+constexpr int kAmaxSpread = 64;
+
+// max over the kAmaxSpread words of utterance b (every lane of the calling wave gets the result)
+__device__ __forceinline__ float amax_read(const float* amax, int b) {
+  float m = amax[b * kAmaxSpread + (threadIdx.x & (kAmaxSpread - 1))];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return m;
+}
 
 // SiLU x*sigmoid(x) (nn.SiLU, reference layers.py:38-39) on the hardware exp2/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each,
 // relative error of the result < 4e-7, far inside the 1e-5 per-op parity gate) -- the fused producers evaluate it for every
@@ -217,7 +229,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
   if (p.amax_out) {      // wave-uniform
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if ((threadIdx.x & 63) == 0) drt_atomic_max_nonneg(p.amax_out + b, vmax);
+    if ((threadIdx.x & 63) == 0)
+      drt_atomic_max_nonneg(p.amax_out + b * kAmaxSpread + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kAmaxSpread - 1)), vmax);
   }
 }
 
@@ -534,7 +547,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs p) {
   if (p.amax_out) {      // every lane of the wave is still here (no early return above)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if ((threadIdx.x & 63) == 0) drt_atomic_max_nonneg(p.amax_out + b, vmax);
+    if ((threadIdx.x & 63) == 0)
+      drt_atomic_max_nonneg(p.amax_out + b * kAmaxSpread + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kAmaxSpread - 1)), vmax);
   }
 }
 

@@ -389,8 +389,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
   // that max |x| 2^s lies in [2^13, 2^14) whatever the range of the stream is
   float xs = 1.f;
   if (S::SCALED) {
-    float m = p.amax1 ? p.amax1[b] : 0.f;
-    if (p.amax2) m = fmaxf(m, p.amax2[b]);
+    float m = p.amax1 ? amax_read(p.amax1, b) : 0.f;
+    if (p.amax2) m = fmaxf(m, amax_read(p.amax2, b));
     xs = h2_weight_scale(m);
   }
 
