@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--cpu-evals", type=int, default=2, help="timed CPU score evaluations for the baseline sample")
+    ap.add_argument("--cpu-evals", type=int, default=8, help="timed CPU score evaluations for the baseline sample")
     return ap.parse_args()
 
 
@@ -72,10 +72,10 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(state, n_evals, N, snr, frames=128):
-    """Oracle (port of the reference's CPU path) on the host cores, B=1.  Bounded sample: the score network is timed on
-    a `frames`-frame slice (1 s of audio for 128) -- its work is linear in the number of frames (fully convolutional in
-    T; attention is 0.08 % of the FLOPs) -- and scaled to the 512-frame, 4 s utterance; 60 evaluations extrapolated."""
+def cpu_baseline(state, n_evals, N, snr, frames=512):
+    """Oracle (port of the reference's CPU path) on the host cores, B=1.  Bounded sample (~10-20 s of CPU work): the score
+    network is timed on `n_evals` full [1,4,256,512] evaluations (a shorter `frames` slice would be scaled linearly: the
+    network is fully convolutional in T and attention is 0.08 % of the FLOPs); 60 evaluations extrapolated."""
     import torch
     from oracle import ncsnpp_oracle as NO, sde_oracle as SO, stft_oracle as FO
     cores = min(usable_cpus(), 32)      # torch's intra-op pool stops scaling (and oversubscribes) far below 256 threads
