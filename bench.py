@@ -217,7 +217,7 @@ def main():
             "dtype": "f32",
             "dtype_note": {0: "exact fp32 MFMA everywhere",
                            1: "fp32 operands and accumulation; wide 3x3 / 1x1 conv products formed from exact 3-way bf16 operand splits on the bf16 MFMA pipe",
-                           2: "fp32 operands and accumulation; wide 3x3 conv products formed from fp16x2 operand splits (1x1: exact bf16x3 splits) on the 16-bit MFMA pipe; "
+                           2: "fp32 operands and accumulation; wide 3x3 / 1x1 conv products formed from fp16x2 operand splits (exact power-of-two scaling) on the f16 MFMA pipe; "
                               "error vs fp64 measured at or below the fp32-MFMA kernels' (DESIGN.md section 3)"}[model.dnn.engine(dev).conv_split_mode()],
             "data": "synthetic (N(0,1) waveforms, random-init weights of the full architecture)",
             "config": {"workload": f"BASELINE {wl['cfg']}: {wl['backbone']} ({model.dnn.engine(dev).param_count() / 1e6:.1f}M params) "
