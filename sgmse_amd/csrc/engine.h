@@ -312,8 +312,43 @@ class Engine {
       off += (kv.second + 63) / 64 * 64;
     }
     if (!on_device) SG_CHECK(drt::stream_sync(stream_));  // host buffers may be released by the caller
+    guard_fp16x2_range(manifest);
     finalize_weights();
   }
+
+  // The fp16x2 3x3 kernel scales its input -- the output of a fused GroupNorm(+SiLU) -- by a fixed 2^4 and saturates at
+  // +-65504, i.e. it presumes |GroupNorm output| < 4094.  A GroupNorm output is bounded by sqrt(N) |gamma| + |beta| (N =
+  // group size; 724 for the largest group at [256, 512]), so the presumption is a guarantee for ordinary affine
+  // parameters.  A checkpoint with extreme ones gets the range-free bf16x3 kernels instead (and a note on stderr).
+  void guard_fp16x2_range(const std::vector<std::pair<std::string, size_t>>& manifest) {
+    read_knobs();                       // a previous load may have downgraded the mode of this context
+    if (split_mode_ != 2) return;
+    float gmax = 0.f, bmax = 0.f;
+    std::vector<float> host;
+    std::map<std::string, int> standalone;       // nn.GroupNorm modules that sit directly in all_modules (output path)
+    for (auto& m : layout_)
+      if (m.kind == Mod::GN) standalone["all_modules." + std::to_string(m.idx) + "."] = 1;
+    auto ends_with = [](const std::string& a, const char* suf) {
+      const size_t n = strlen(suf);
+      return a.size() >= n && a.compare(a.size() - n, n, suf) == 0;
+    };
+    for (auto& kv : manifest) {
+      const bool is_w = ends_with(kv.first, ".weight"), is_b = ends_with(kv.first, ".bias");
+      if (!is_w && !is_b) continue;
+      const std::string prefix = kv.first.substr(0, kv.first.size() - (is_w ? 6 : 4));
+      if (kv.first.find("GroupNorm") == std::string::npos && !standalone.count(prefix)) continue;
+      host.resize(kv.second);
+      SG_CHECK(drt::memcpy_d2h(host.data(), W_.at(kv.first), kv.second * 4, stream_));
+      SG_CHECK(drt::stream_sync(stream_));
+      for (float v : host) { if (is_w) gmax = std::max(gmax, std::fabs(v)); else bmax = std::max(bmax, std::fabs(v)); }
+    }
+    if (!(gmax <= kH2GammaLimit && bmax <= kH2BetaLimit)) {      // also catches NaN
+      split_mode_ = 1;
+      fprintf(stderr, "sgmse: GroupNorm affine parameters out of the fp16x2 kernel's guaranteed range (max|gamma| = %g, max|beta| = %g): "
+                      "using the bf16x3 kernels for this model\n", gmax, bmax);
+    }
+  }
+  static constexpr float kH2GammaLimit = 4.0f, kH2BetaLimit = 64.0f;    // 724 * 4 + 64 < 4094
 
   size_t param_count() const { size_t n = 0; for (auto& kv : param_manifest(cfg_)) n += kv.second; return n; }
 
