@@ -279,6 +279,20 @@ def test_full_size_forward_against_oracle(hip):
     assert rel_l2(out.cpu(), ref) < P.NET_TOL
 
 
+def test_full_width_48k_forward_against_oracle(hip):
+    """ncsnpp_48k at full width (F = 768, no pyramids, bottleneck attention only) with the split kernels on its wide
+    levels, against the CPU oracle."""
+    cfg = NO.NetCfg.for_variant("ncsnpp_48k")
+    net, Pm = P.make_backbone(cfg, hip)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 2, 768, 128, dtype=torch.complex64, generator=g) * 0.3
+    t = torch.tensor([0.8, 0.11])
+    with torch.no_grad():
+        ref = NO.ncsnpp_forward(Pm, cfg, x, t)
+    out = net(x.to(hip), t.to(hip))
+    assert rel_l2(out.cpu(), ref) < P.NET_TOL
+
+
 def test_full_size_batch_independence(hip):
     """Size-independent property at the bench shape: utterances never interact, so a batched evaluation equals the
     per-utterance evaluations bit for bit, in any batch position."""
