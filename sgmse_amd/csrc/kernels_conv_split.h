@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
 // fragments, B through LDS, A from global), but a K-stage is only one MFMA K-step deep (16 channels, no taps), so the
 // global loads of a stage are issued TWO stages ahead (register sets rinA / rinB) and the producer + split of stage
 // s+1 is spread over the pixel fragments of stage s.  Inputs of these layers are raw residual-stream activations of
-// unknown range: the engine uses the range-free bf16x3 policy here.
+// unknown range: bf16x3 needs no range; fp16x2 scales by an exact power of two derived per utterance from the range
+// bounds the producing kernels left behind (ConvArgs::amax1/amax2), so that max|x| 2^s lies in [2^13, 2^14).
 template <class S>
 __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
   using T = ConvTile<1, 4, 1, 8, 1>;
