@@ -5,6 +5,7 @@ import math
 import os
 
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -373,3 +374,40 @@ def check_weight_reload(dev):
     net.mark_weights_changed()
     b = net(x, t)
     assert torch.equal(b, 2.0 * a)
+
+
+def check_enhancement_script(dev, tmp_path, monkeypatch):
+    """python -m sgmse_amd.enhancement: checkpoint + directory of wav files -> enhanced directory (batched by length,
+    seeded noise reproducible, rank sharding covers every file exactly once)."""
+    from scipy.io import wavfile
+    from sgmse_amd import enhancement as E
+    from sgmse_amd.model import ScoreModel
+    from sgmse_amd.data_module import SpecsDataModule
+    hp = dict(backbone="ncsnpp", sde="ouve", nf=32, theta=1.5, sigma_min=0.05, sigma_max=0.5, N=30, t_eps=0.03,
+              data_module_cls=SpecsDataModule, n_fft=510, hop_length=128, spec_factor=0.15, spec_abs_exponent=0.5)
+    src = ScoreModel(**hp)
+    src.dnn.load_state_dict(synth.synth_params(NET_CASES["fwd_nf32"], seed=0))
+    ckpt = tmp_path / "m.ckpt"
+    torch.save({"state_dict": {"dnn." + k: v.clone() for k, v in src.dnn.state_dict().items()}, "hyper_parameters": hp}, ckpt)
+    noisy = tmp_path / "noisy"
+    (noisy / "sub").mkdir(parents=True)
+    rng = torch.Generator().manual_seed(5)
+    lengths = {"a.wav": 2000, "b.wav": 2000, "sub/c.wav": 2600}
+    for name, L in lengths.items():
+        wavfile.write(str(noisy / name), 16000, (0.1 * torch.randn(L, generator=rng)).numpy())
+    base = ["--test_dir", str(noisy), "--ckpt", str(ckpt), "--device", str(dev), "--N", "2", "--seed", "7"]
+    with pytest.warns(UserWarning):          # checkpoint without EMA weights (model.py:106)
+        assert E.main(base + ["--enhanced_dir", str(tmp_path / "o1")]) == 3
+        assert E.main(base + ["--enhanced_dir", str(tmp_path / "o2"), "--batch_size", "2"]) == 3
+    for name, L in lengths.items():
+        sr, x1 = wavfile.read(str(tmp_path / "o1" / name))
+        _, x2 = wavfile.read(str(tmp_path / "o2" / name))
+        assert sr == 16000 and x1.shape == (L,) and np.isfinite(x1).all() and np.abs(x1).max() > 0
+        assert np.array_equal(x1, x2)        # same seed, same batching -> same noise -> same waveform
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    seen = 0
+    with pytest.warns(UserWarning):
+        for r in (0, 1):
+            monkeypatch.setenv("RANK", str(r))
+            seen += E.main(base + ["--enhanced_dir", str(tmp_path / "o3")])
+    assert seen == 3 and sorted(str(p.relative_to(tmp_path / "o3")) for p in (tmp_path / "o3").rglob("*.wav")) == sorted(lengths)

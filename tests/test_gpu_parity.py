@@ -312,6 +312,10 @@ def test_conv_tile_shape_never_changes_a_bit(hip):
     P.check_tile_independence(hip, "fwd_nf32")
 
 
+def test_enhancement_script_directory_to_directory(hip, tmp_path, monkeypatch):
+    P.check_enhancement_script(hip, tmp_path, monkeypatch)
+
+
 def test_error_behaviour(hip):
     from sgmse_amd import ops
     with pytest.raises(ValueError):
