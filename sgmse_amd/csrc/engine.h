@@ -1047,6 +1047,11 @@ class Engine {
     if (emit_stats && use_mfma && fuse_gn_stats_) {
       o.nsub = conv_plan_nsub(a.H, a.W);
       o.st = arena_.alloc((size_t)B_ * w.cout * o.nsub * 2);
+    } else if (emit_stats && fuse_gn_stats_) {
+      // direct kernel: one statistics pass right behind it, kept with the tensor -- these outputs (entry conv, Combine)
+      // are normalised twice, by the next block and again as skip connections on the way up
+      o.nsub = 1;
+      o.st = arena_.alloc((size_t)B_ * w.cout * 2);
     }
     o.amax = next_amax();
     if (dry_) return o;
@@ -1078,8 +1083,15 @@ class Engine {
       tick(w.ks == 3 ? ((split_mode_ == 0 && co_t == 128 && pl.rows == 8) ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else {
       ca.w = w.oihw;
+      ca.stats_out = nullptr;
       launch_conv_direct(ca, w.ks, stream_);
       tick(TC_DIRECT, fl);
+      if (o.st) {
+        tock();
+        DRT_LAUNCH(gn_chan_stats_kernel, dim3(B_ * w.cout), dim3(256), stream_, (const float*)o.p, (const float*)nullptr, w.cout, 0,
+                   a.H * a.W, o.st);
+        tick(TC_GN, 4.0 * B_ * (double)w.cout * a.H * a.W, 1);
+      }
     }
     return o;
   }
@@ -1190,7 +1202,7 @@ class Engine {
     {
       const Mod& m = next();
       const ConvW& w = conv_.at(m.idx);
-      hs.push_back(conv(w, xr, nullptr, Xform{}, w.bias, nullptr, nullptr, 1.f, ctl));
+      hs.push_back(conv(w, xr, nullptr, Xform{}, w.bias, nullptr, nullptr, 1.f, ctl, true));
     }
     Tensor pyr_in = xr;   // input pyramid (ncsnpp.py:293-296); released at the end / when replaced
     bool pyr_in_is_xr = true;
@@ -1215,7 +1227,7 @@ class Engine {
           if (!pyr_in_is_xr) drop(pyr_in);
           pyr_in = np; pyr_in_is_xr = false;
           const ConvW& w = conv_.at(mc.idx);
-          Tensor h2 = conv(w, pyr_in, nullptr, Xform{}, w.bias, nullptr, h.p, 1.f, ctl);
+          Tensor h2 = conv(w, pyr_in, nullptr, Xform{}, w.bias, nullptr, h.p, 1.f, ctl, true);
           drop(h);
           h = h2;
         }
