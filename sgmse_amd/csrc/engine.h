@@ -926,10 +926,13 @@ class Engine {
         for (float2** q : {&sx_, &sxm_, &sscore_, &sy_}) { if (*q) dev_free_owned(*q); *q = static_cast<float2*>(dev_alloc(n * 8)); }
         samp_n_ = n;
       }
-      if (B > amax_pool_B_) {
+      // range-bound slots: one per convolution output of the forward just dry-run
+      const size_t need_amax = (size_t)amax_next_ * B * kAmaxSpread;
+      amax_slots_ = amax_next_;
+      if (need_amax > amax_pool_floats_) {
         if (amax_pool_) dev_free_owned(amax_pool_);
-        amax_pool_ = static_cast<float*>(dev_alloc((size_t)kAmaxSlots * B * kAmaxSpread * 4));
-        amax_pool_B_ = B;
+        amax_pool_ = static_cast<float*>(dev_alloc(need_amax * 4));
+        amax_pool_floats_ = need_amax;
       }
       if (!step_ctr_) step_ctr_ = static_cast<int*>(dev_alloc(256));
       if (!lang_scal_) lang_scal_ = static_cast<float*>(dev_alloc(256));
@@ -1186,7 +1189,7 @@ class Engine {
     B_ = B;
     amax_next_ = 0;
     if (!dry_ && amax_pool_) {
-      const int n = kAmaxSlots * B * kAmaxSpread;
+      const int n = amax_slots_ * B * kAmaxSpread;
       DRT_LAUNCH(zero_floats_kernel, dim3((n + 255) / 256), dim3(256), stream_, amax_pool_, n);
     }
     const NetCfg& c = cfg_;
@@ -1339,12 +1342,13 @@ class Engine {
     split_min_tiles_ = e ? atol(e) : 8L;                    // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
   }
-  static constexpr int kAmaxSlots = 256;     // per-forward range-bound slots ([B][kAmaxSpread] floats each), handed out in program order
-  float* amax_pool_ = nullptr; int amax_pool_B_ = 0, amax_next_ = 0;
+  // per-forward range-bound slots ([B][kAmaxSpread] floats each), handed out in program order; counted by the dry run
+  float* amax_pool_ = nullptr; size_t amax_pool_floats_ = 0; int amax_slots_ = 0, amax_next_ = 0;
   float* next_amax() {
-    SG_REQUIRE(amax_next_ < kAmaxSlots, "amax pool exhausted");
     const int i = amax_next_++;
-    return amax_pool_ ? amax_pool_ + (size_t)i * B_ * kAmaxSpread : nullptr;
+    if (dry_) return nullptr;
+    SG_REQUIRE(amax_pool_ && i < amax_slots_, "range-bound pool smaller than the forward needs");
+    return amax_pool_ + (size_t)i * B_ * kAmaxSpread;
   }
   long tile_min_blocks_ = 512, split_min_tiles_ = 8;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
