@@ -85,11 +85,18 @@ inline bool conv_thin_split_eligible(int ks, int C1, int C2, int Cout) {
   return ks == 3 && Cout <= 32 && (C1 + C2) >= 64 && (C1 + C2) % 16 == 0 && (C2 == 0 || C1 % 16 == 0) && (C1 + C2) <= 512;
 }
 // mode 1: bf16x3, mode 2: fp16x2 (a.acc_scale must point at the factor stored behind the packed weights)
-inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t st) {
+// rows4: the 4-row workgroup shape of the full 3x3 kernel (same results; for launches that cannot fill the chip)
+inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t st, bool rows4 = false) {
   const int tiles = a.B * ((a.H + 7) / 8) * ((a.W + 31) / 32);
+  if (ks == 3 && a.Cout > 32 && rows4) {
+    const int tiles4 = a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32);
+    if (mode == 2) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2>), dim3(tiles4, a.Cout / 128, 1), dim3(256), st, a);
+    else DRT_LAUNCH((conv3x3_split_kernel<SplitB3, 2>), dim3(tiles4, a.Cout / 128, 1), dim3(256), st, a);
+    return;
+  }
   if (ks == 3 && a.Cout <= 32) {
-    if (mode == 2) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, true>), dim3(tiles, 1, 1), dim3(256), st, a);
-    else DRT_LAUNCH((conv3x3_split_kernel<SplitB3, true>), dim3(tiles, 1, 1), dim3(256), st, a);
+    if (mode == 2) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 1>), dim3(tiles, 1, 1), dim3(256), st, a);
+    else DRT_LAUNCH((conv3x3_split_kernel<SplitB3, 1>), dim3(tiles, 1, 1), dim3(256), st, a);
     return;
   }
   if (ks == 1) {
@@ -97,8 +104,8 @@ inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t
     else DRT_LAUNCH(conv1x1_split_kernel<SplitB3>, dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
     return;
   }
-  if (mode == 2) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, false>), dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
-  else DRT_LAUNCH((conv3x3_split_kernel<SplitB3, false>), dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
+  if (mode == 2) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 0>), dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
+  else DRT_LAUNCH((conv3x3_split_kernel<SplitB3, 0>), dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
 }
 
 inline void launch_conv_direct(const ConvArgs& a, int ks, drt::stream_t st) {

@@ -1071,7 +1071,9 @@ class Engine {
     if (use_split) {
       ca.w = w.packed_split; ca.acc_scale = w.split_scale;
       if (w.ks == 1 && w.split_mode == 2) { ca.amax1 = a.amax; ca.amax2 = b ? b->amax : nullptr; }
-      launch_conv_split(ca, w.ks, w.split_mode, stream_);
+      // 4-row workgroups when 8-row ones would leave CUs idle (bit-identical results, so this may follow the batch size)
+      const long nblk8 = (long)B_ * ((a.H + 7) / 8) * ((a.W + 31) / 32) * ((w.cout + 127) / 128);
+      launch_conv_split(ca, w.ks, w.split_mode, stream_, /*rows4=*/nblk8 < tile_min_blocks_);
       if (prof_ && prof_dump_)
         snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "");
       tick(w.ks == 3 ? (w.cout >= 128 ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);

@@ -76,10 +76,11 @@ struct SplitH2 {
 };
 constexpr float kH2XScale = 16.f;
 
+template <int ROWS_>
 struct ConvSplitGeom {
-  static constexpr int KC = 16, ROWS = 8, TROWS = 10, TCOLS = 34;
+  static constexpr int KC = 16, ROWS = ROWS_, TROWS = ROWS_ + 2, TCOLS = 34;
   static constexpr int NITEM = TROWS * TCOLS * 2;              // (pixel, k-group) staging items per stage
-  static constexpr int NIT = (NITEM + 255) / 256;              // per thread (3)
+  static constexpr int NIT = (NITEM + 255) / 256;              // per thread (3 for 8 rows, 2 for 4)
 };
 
 // Weight packing.  src: OIHW fp32 [Cout][Cin][k][k] (taps = k*k = 9 or 1); dst: u32x4 [nCoBlk][Cin/16][taps][NS][4][64], followed (SplitH2) by
@@ -148,18 +149,24 @@ inline size_t packed_split_frags(int cin, int cout, int taps = 9) { return (size
 template <class S>
 inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<S>(cin, cout) * 16 + 16; }
 
-// THIN = false: the four waves own the four 32-channel fragments of a 128-channel block, each all 8 pixel fragments.
-// THIN = true (Cout <= 32, the C->4 pyramid convolutions): one 32-channel fragment (zero-padded weights), the four waves
-// own two pixel fragments each -- 1/4 of the MFMA work of a full block for the same staged tile; these layers are bound
-// by the producer arithmetic and HBM, not by the matrix pipe.
-template <class S, bool THIN = false>
+// Workgroup shapes (all with the same K order, epilogue and per-row GroupNorm partials: bit-identical results):
+//   SHAPE 0: the four waves own the four 32-channel fragments of a 128-channel block, each all 8 pixel fragments
+//            (128 co x 8 rows x 32 px).
+//   SHAPE 1 (Cout <= 32, the C->4 pyramid convolutions): one 32-channel fragment (zero-padded weights), the four waves
+//            own two pixel fragments each -- 1/4 of the MFMA work of a full block for the same staged tile; these layers
+//            are bound by the producer arithmetic and HBM, not by the matrix pipe.
+//   SHAPE 2: as 0 with 4 rows (128 co x 4 rows x 32 px): twice the workgroups of half the duration, for launches that
+//            cannot fill the chip (small batches: the per-file loop of enhancement.py).
+template <class S, int SHAPE = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
-  using C = ConvSplitGeom;
-  // epilogue geometry: 4 channel-waves x 1 fragment x 8 pixel fragments, or 1 channel-wave, 4 pixel-waves x 2 fragments
-  using T = std::conditional_t<THIN, ConvTile<3, 1, 1, 2, 1>, ConvTile<3, 4, 1, 8, 1>>;
-  static_assert(T::CO_T == (THIN ? 32 : 128) && T::ROWS == 8, "tile");
+  constexpr bool THIN = SHAPE == 1;
+  constexpr int ROWS = SHAPE == 2 ? 4 : 8;
+  using C = ConvSplitGeom<ROWS>;
+  // epilogue geometry: 4 channel-waves x 1 fragment x ROWS pixel fragments, or 1 channel-wave, 4 pixel-waves x 2 fragments
+  using T = std::conditional_t<THIN, ConvTile<3, 1, 1, 2, 1>, ConvTile<3, 4, 1, ROWS, 1>>;
+  static_assert(T::CO_T == (THIN ? 32 : 128) && T::ROWS == ROWS, "tile");
   constexpr int NS = S::NS, PX_V = S::PX_V;
-  constexpr int FPW = THIN ? 2 : 8;        // pixel fragments per wave
+  constexpr int FPW = THIN ? 2 : ROWS;     // pixel fragments per wave
   constexpr int EPJ = 8 / FPW;             // producer elements staged behind each fragment's MFMAs
   constexpr int STAGE_V = C::TROWS * C::TCOLS * PX_V;
   __shared__ u32x4 s_in0[STAGE_V];
@@ -171,13 +178,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   const int Cin = p.C1 + p.C2;
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
-  const int tiles_y = (H + 7) >> 3;
+  const int tiles_y = (H + ROWS - 1) / ROWS;
   int bid = blockIdx.x;
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
   const int co_blk = blockIdx.y;
-  const int x0 = tx * 32, y0 = ty * 8;
+  const int x0 = tx * 32, y0 = ty * ROWS;
   const bool xform = p.in_scale != nullptr;
   for (int c = tid; c < Cin; c += 256) {
     s_sc[c] = xform ? p.in_scale[b * Cin + c] : 1.f;
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       if (tap & 1) load_a(nstg, ntap, a0); else load_a(nstg, ntap, a1);
       if (tap < C::NIT) load_item(tap, stn * C::KC);
       __builtin_amdgcn_sched_barrier(0);
-      const int item = (tap >= 4 && (tap & 1) == 0) ? (tap - 4) / 2 : -1;     // taps 4, 6, 8 stage items 0, 1, 2
+      const int item = (tap >= 4 && (tap & 1) == 0 && (tap - 4) / 2 < C::NIT) ? (tap - 4) / 2 : -1;   // taps 4, 6, 8: items 0, 1, 2
       if (tap & 1) compute_tap(cur, tap, a1, item, stn * C::KC, nxt); else compute_tap(cur, tap, a0, item, stn * C::KC, nxt);
     }
     __syncthreads();
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   }
 
   if constexpr (THIN) conv_epilogue<T, 1, FPW, 1>(p, acc, b, co_blk, tx, ty, tiles_x, 0, wave, l31, kg);
-  else conv_epilogue<T, 1, 8, 4>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);
+  else conv_epilogue<T, 1, FPW, 4>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

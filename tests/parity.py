@@ -216,6 +216,31 @@ def check_forward_b3_everywhere(dev, name="fwd_nf128", mode=None):
                 os.environ[k] = v
 
 
+def check_split_workgroup_shapes_bitwise(dev, name="fwd_nf128"):
+    """The split kernels' 8-row and 4-row workgroup shapes (chosen by workgroup count, i.e. by batch size) give the same
+    bits: full-width network with a split kernel on every eligible layer, widest vs narrowest shapes everywhere."""
+    cfg = NET_CASES[name]
+    z = load(name)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    keys = ("SGMSE_SPLIT_MIN_TILES", "SGMSE_TILE_MIN_BLOCKS")
+    old = {k: os.environ.get(k) for k in keys}
+    outs = []
+    try:
+        os.environ["SGMSE_SPLIT_MIN_TILES"] = "1"
+        for m in ("1", "1000000000"):
+            os.environ["SGMSE_TILE_MIN_BLOCKS"] = m
+            net, _ = make_backbone(cfg, dev)
+            outs.append(net(x.to(dev), t.to(dev)).cpu())
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[0], torch.from_numpy(z["out"])) < NET_TOL
+
+
 def make_model(cfg, dev, P=None, sde="ouve", **kw):
     from sgmse_amd.model import ScoreModel
     P = synth.synth_params(cfg, seed=0) if P is None else P

@@ -166,6 +166,12 @@ def test_forward_with_split_kernels_on_every_eligible_layer(emu, mode):
 
 @pytest.mark.slow
 @pytest.mark.skipif(not os.environ.get("SGMSE_SLOW"), reason="full-width network on the emulator (minutes); set SGMSE_SLOW=1")
+def test_split_kernel_workgroup_shapes_give_the_same_bits(emu):
+    P.check_split_workgroup_shapes_bitwise(emu)
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get("SGMSE_SLOW"), reason="full-width network on the emulator (minutes); set SGMSE_SLOW=1")
 def test_forward_matches_reference_full_width(emu):
     P.check_forward_golden(emu, "fwd_nf128")
 

@@ -111,6 +111,10 @@ def test_forward_with_split_kernels_on_every_eligible_layer(hip, mode):
     P.check_forward_b3_everywhere(hip, mode=mode)
 
 
+def test_split_kernel_workgroup_shapes_give_the_same_bits(hip):
+    P.check_split_workgroup_shapes_bitwise(hip)
+
+
 def test_conv1x1_wide_output(hip):
     """1x1 convolutions with 128-channel output blocks: ragged edges, concat, fused producer (the streaming variant of
     the same shapes runs under SGMSE_CONV_VARIANT=8 in test_conv_kernel_variants)."""
