@@ -86,17 +86,21 @@ inline bool conv_thin_split_eligible(int ks, int C1, int C2, int Cout) {
 }
 // mode 1: bf16x3, mode 2: fp16x2 (a.acc_scale must point at the factor stored behind the packed weights)
 // rows4: the 4-row workgroup shape of the full 3x3 kernel (same results; for launches that cannot fill the chip)
-inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t st, bool rows4 = false) {
+// abl: measurement-only ablation instantiations of the dominant shape (fp16x2, 8 rows, SiLU producer), see the kernel
+template <class S, int SHAPE>
+inline void launch_conv3x3_split_t(const ConvArgs& a, dim3 grid, drt::stream_t st) {
+  if (a.in_scale && a.in_act) DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1>), grid, dim3(256), st, a);
+  else DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 0>), grid, dim3(256), st, a);
+}
+inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t st, bool rows4 = false, int abl = 0) {
   const int tiles = a.B * ((a.H + 7) / 8) * ((a.W + 31) / 32);
   if (ks == 3 && a.Cout > 32 && rows4) {
-    const int tiles4 = a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32);
-    if (mode == 2) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2>), dim3(tiles4, a.Cout / 128, 1), dim3(256), st, a);
-    else DRT_LAUNCH((conv3x3_split_kernel<SplitB3, 2>), dim3(tiles4, a.Cout / 128, 1), dim3(256), st, a);
+    const dim3 grid(a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32), a.Cout / 128, 1);
+    if (mode == 2) launch_conv3x3_split_t<SplitH2, 2>(a, grid, st); else launch_conv3x3_split_t<SplitB3, 2>(a, grid, st);
     return;
   }
   if (ks == 3 && a.Cout <= 32) {
-    if (mode == 2) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 1>), dim3(tiles, 1, 1), dim3(256), st, a);
-    else DRT_LAUNCH((conv3x3_split_kernel<SplitB3, 1>), dim3(tiles, 1, 1), dim3(256), st, a);
+    if (mode == 2) launch_conv3x3_split_t<SplitH2, 1>(a, dim3(tiles, 1, 1), st); else launch_conv3x3_split_t<SplitB3, 1>(a, dim3(tiles, 1, 1), st);
     return;
   }
   if (ks == 1) {
@@ -104,8 +108,13 @@ inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t
     else DRT_LAUNCH(conv1x1_split_kernel<SplitB3>, dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
     return;
   }
-  if (mode == 2) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 0>), dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
-  else DRT_LAUNCH((conv3x3_split_kernel<SplitB3, 0>), dim3(tiles, a.Cout / 128, 1), dim3(256), st, a);
+  const dim3 grid(tiles, a.Cout / 128, 1);
+  if (abl && mode == 2) {
+#define SGMSE_ABL_CASE(V) if (abl == V) { DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 0, 1, V>), grid, dim3(256), st, a); return; }
+    SGMSE_ABL_CASE(3) SGMSE_ABL_CASE(4) SGMSE_ABL_CASE(8) SGMSE_ABL_CASE(24) SGMSE_ABL_CASE(56) SGMSE_ABL_CASE(59)
+#undef SGMSE_ABL_CASE
+  }
+  if (mode == 2) launch_conv3x3_split_t<SplitH2, 0>(a, grid, st); else launch_conv3x3_split_t<SplitB3, 0>(a, grid, st);
 }
 
 inline void launch_conv_direct(const ConvArgs& a, int ks, drt::stream_t st) {

@@ -659,8 +659,12 @@ class Engine {
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
     SG_REQUIRE(pl.mfma, "bench_conv: shape is not MFMA-eligible");
     if (variant >= 0 && (variant & 512)) { pl.rows = 4; variant &= ~512; }   // measurement knob: 128 co x 128 px tile
-    int ablate = 0;
-    if (variant >= 0) { ablate = (variant >> 12) & 15; variant &= 4095; }       // measurement knob: ablation bits 12..15
+    int ablate = 0, abl_split = 0;
+    if (variant >= 0) {
+      abl_split = (variant >> 16) & 63;          // measurement knob: compile-time ablation of the split 3x3 kernel, bits 16..21
+      ablate = (variant >> 12) & 15;             // measurement knob: run-time ablation of the fp32 kernels, bits 12..15
+      variant &= 4095;
+    }
     const int smode = variant < 0 ? 0 : ((variant & 128) ? 2 : ((variant & 64) ? 1 : 0));
     const bool b3 = smode != 0;
     SG_REQUIRE(!b3 || conv_split_eligible(ks, Cin, 0, Cout), "bench_conv: shape is not eligible for the split kernels");
@@ -695,7 +699,7 @@ class Engine {
         a.amax1 = bounds;
       }
     }
-    auto go = [&]() { if (b3) launch_conv_split(a, ks, smode, stream_); else launch_conv_mfma(a, ks, pl, stream_, variant); };
+    auto go = [&]() { if (b3) launch_conv_split(a, ks, smode, stream_, false, abl_split); else launch_conv_mfma(a, ks, pl, stream_, variant); };
     for (int i = 0; i < 2; ++i) go();
     drt::event_record(&e0, stream_);
     for (int i = 0; i < iters; ++i) go();

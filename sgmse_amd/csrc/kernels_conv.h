@@ -58,8 +58,8 @@ struct ConvArgs {
   // per-utterance range bounds of src1 / src2 ([B][kAmaxSpread] each, from the producers' amax_out) for a consumer that
   // scales its input dynamically (conv1x1_split_kernel<SplitH2>); null otherwise
   const float* amax1; const float* amax2;
-  // measurement-only ablation switches for sgmse_bench_conv (results are then WRONG on purpose): bit 0 skip the
-  // epilogue's global stores, bit 1 skip the residual read, bit 2 stage only the first K-stage, bit 3 skip the barriers
+  // measurement-only ablation switches of the fp32 kernels for sgmse_bench_conv (results are then WRONG on purpose):
+  // bit 2 stage only the first K-stage, bit 3 skip the barriers (the epilogue's switches are compile-time: conv_epilogue<ABL>)
   int ablate;
 };
 
@@ -103,128 +103,182 @@ struct ConvTile {
   static constexpr int NW4 = (W_ELEMS / 4 + 255) / 256;
 };
 
+// Accumulator initialisation with the per-channel additive terms of the epilogue, (bias + time-embedding row) / as, so that
+// their loads overlap the first K-stage's loads instead of delaying the epilogue and the epilogue neither holds 16 bias
+// registers nor adds them (as = the power of two that takes the accumulator back to the unscaled convolution: the
+// division is exact).  Returns the value for accumulator register r of every pixel fragment of channel fragment `frag`.
+template <class T>
+__device__ __forceinline__ void conv_acc_init(const ConvArgs& p, int b, int co_blk, int frag, int kh, float as_mul, float (&init)[16]) {
+  const float as = (p.acc_scale ? *p.acc_scale : 1.0f) * as_mul;
+  const float inv = 1.0f / as;
+  const float* b2 = nullptr;
+  if (p.bias2) {
+    const int step = p.step_ptr ? *p.step_ptr : 0;
+    b2 = p.bias2 + (size_t)step * p.bias2_sstride + (size_t)b * p.bias2_bstride;
+  }
+  const int co_l = co_blk * T::CO_T + frag * 32 + 4 * kh;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) init[r] = 0.f;
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int co = co_l + (r & 3) + 8 * (r >> 2); init[r] = p.bias[co < p.Cout ? co : 0]; }
+  }
+  if (b2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int co = co_l + (r & 3) + 8 * (r >> 2); init[r] += b2[co < p.Cout ? co : 0]; }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) init[r] *= inv;
+}
+
 // Epilogue shared by the MFMA kernels: D[co = regs][px = lanes] -> NCHW rows, + bias, + time-embedding bias row,
 // + residual, * out_scale, and (optionally) the per-(b, co, sub-tile) GroupNorm partial sums of the stored values.
-template <class T, int FC, int FP, int WC>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[FC][FP], int b, int co_blk, int tx, int ty,
-                                              int tiles_x, int wc, int wp, int l31, int kh, float as_mul = 1.0f) {
+//
+// Addressing: a lane's byte offset inside its utterance is lane_boff + j W 4 (one VGPR per fragment row) plus
+// ((r&3) + 8 (r>>2)) H W 4, the same for every lane (16 SGPRs shared by the output and the residual), so every access is
+// one raw-buffer instruction `base + VGPR offset + SGPR offset` with no address arithmetic on the vector ALU.  GUARD = false is the fast path of a wave whose 32 output channels, FP rows and
+// 32 columns all lie inside the tensor (wave-uniform test); GUARD = true predicates every access.
+// GroupNorm partials: one {sum, sum of squares} per (channel, image row, 32-pixel segment), reduced over the 32 lanes
+// of the segment by an exchange-add butterfly (drt_xadd: v_permlane16_swap / DPP, no LDS traffic): after the steps
+// 16, 8, 7 (mirror), 1 a lane owns ONE of the 16 registers summed over 16 lanes, and the final ^2 step completes it.
+// The order of the additions is a function of (row, segment) only -- not of the tile shape, wave or workgroup -- so the
+// statistics, and everything computed from them, do not depend on which tile shape a launch used.
+template <class T, int FC, int FP, int WC, bool GUARD, int ABL, bool PRE, bool RES>
+__device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&acc)[FC][FP], int b, int co_blk, int tx, int ty,
+                                                    int tiles_x, int wc, int wp, int l31, int kh, float as) {
   constexpr int CO_T = T::CO_T, ROWS = T::ROWS;
+  constexpr int PF = FP < 4 ? FP : 4;           // residual rows in flight (16 registers each)
   const int H = p.H, W = p.W;
-  const int x0 = tx * 32, y0 = ty * ROWS;
-  const int x = x0 + l31;
-  const float as = (p.acc_scale ? *p.acc_scale : 1.0f) * as_mul;     // exact powers of two (or 1)
+  const unsigned HW = (unsigned)H * (unsigned)W;
+  const int x = tx * 32 + l31;
+  const int yb = ty * ROWS + wp * FP;            // first image row of this wave
+  const bool xok = !GUARD || x < W;
+  const size_t ubase = (size_t)b * p.Cout * HW;  // uniform
+  const drt_buf obuf = drt_make_buf(p.out + ubase), rbuf = drt_make_buf(RES ? p.res + ubase : p.out);
   float vmax = 0.f;
   const float* b2 = nullptr;
   if (p.bias2) {
     const int step = p.step_ptr ? *p.step_ptr : 0;
     b2 = p.bias2 + (size_t)step * p.bias2_sstride + (size_t)b * p.bias2_bstride;
   }
+  constexpr bool has_res = RES;
 #pragma unroll
   for (int i = 0; i < FC; ++i) {
-    const int co_base = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh;
+    const int co0 = co_blk * CO_T + (wc * FC + i) * 32;                       // uniform
+    const int co_l = co0 + 4 * kh;                                            // + (r&3) + 8 (r>>2)
+    // byte offset of (channel co_l, row yb, column x) inside the utterance; < 2^31 for every tensor of this network
+    const unsigned lane_boff = (((unsigned)co_l * (unsigned)H + (unsigned)yb) * (unsigned)W + (unsigned)x) * 4u;
+    auto soff = [&](int r) -> unsigned { return (unsigned)((r & 3) + 8 * (r >> 2)) * HW * 4u; };
+    // per-channel additive terms (conv bias + time-embedding row): two batches of independent loads, each under ONE uniform
+    // branch (a branch per element serialises 32 loads behind vmcnt(0) waits); PRE: already in the accumulators
     float bv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co_base + (r & 3) + 8 * (r >> 2);
-      float t = 0.f;
-      if (co < p.Cout) {
-        if (p.bias) t += p.bias[co];
-        if (b2) t += b2[co];
+    for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+    if constexpr (!PRE) {
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_l + (r & 3) + 8 * (r >> 2);
+          bv[r] = p.bias[(!GUARD || co < p.Cout) ? co : 0];
+        }
       }
-      bv[r] = t;
+      if (b2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_l + (r & 3) + 8 * (r >> 2);
+          bv[r] += b2[(!GUARD || co < p.Cout) ? co : 0];
+        }
+      }
     }
-    // residual: the 16 values of fragment row j+1 are loaded (independent, unconditional, clamped addresses) before the
-    // adds and stores of row j -- issued one by one behind their dependent add + store, the residual read cost 11 % of the
-    // kernel (profiles/r01_conv_ablation.txt); a whole-column batch (FP*16 registers) spills
-    const bool has_res = p.res && !(p.ablate & 2);
-    float rr[2][16];
+    // residual rows are loaded PF - 1 fragment rows ahead of their use (independent loads; issued one by one behind their
+    // dependent add + store the residual read cost 11 % of the fp32 kernel, profiles/r01_conv_ablation.txt)
+    float rr[PF][16];
     auto load_res = [&](int j, int slot) {
-      const int y = y0 + wp * FP + j;
-      const bool pok = y < H && x < W;
+      const bool rok = !GUARD || (yb + j < H && xok);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co_base + (r & 3) + 8 * (r >> 2);
-        const bool ok = pok && co < p.Cout;
-        const size_t o = ok ? ((size_t)(b * p.Cout + co) * H + y) * W + x : 0;
-        const float t = p.res[o];
-        rr[slot][r] = ok ? t : 0.f;
+        const bool ok = rok && (!GUARD || co_l + (r & 3) + 8 * (r >> 2) < p.Cout);
+        float t = 0.f;
+        if (ok) t = drt_buf_load(rbuf, lane_boff + (unsigned)j * (unsigned)W * 4u, soff(r));
+        rr[slot][r] = t;
       }
     };
+    if constexpr (has_res) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { rr[0][r] = 0.f; rr[1][r] = 0.f; }
-    if (has_res) load_res(0, 0);          // wave-uniform branch: layers without a residual pay nothing
+      for (int j = 0; j < PF - 1; ++j) load_res(j, j);
+    }
 #pragma unroll
     for (int j = 0; j < FP; ++j) {
-      if (has_res && j + 1 < FP) load_res(j + 1, (j + 1) & 1);
-      const int y = y0 + wp * FP + j;
-      const bool pok = y < H && x < W;
-      float sv[16], sq[16];
+      if constexpr (has_res) { if (j + PF - 1 < FP) load_res(j + PF - 1, (j + PF - 1) % PF); }
+      const int y = yb + j;
+      const bool rok = !GUARD || (y < H && xok);
+      float sv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co_base + (r & 3) + 8 * (r >> 2);
-        float v = (acc[i][j][r] * as + bv[r] + rr[j & 1][r]) * p.out_scale;
-        const bool ok = pok && co < p.Cout;
-        if (ok) {
-          const size_t o = ((size_t)(b * p.Cout + co) * H + y) * W + x;
-          if (!(p.ablate & 1)) p.out[o] = v;
-          else if (v == 12345.678f) p.out[o] = v;   // keeps the value live without storing
-        }
-        v = ok ? v : 0.f;
+        float v = acc[i][j][r] * as;
+        if constexpr (!PRE) v += bv[r];
+        if constexpr (has_res) v += rr[j % PF][r];
+        v *= p.out_scale;
+        const bool ok = rok && (!GUARD || co_l + (r & 3) + 8 * (r >> 2) < p.Cout);
+        if (ok && (!(ABL & 1) || v == 12345.678f))      // ABL bit 0 (measurement only): keep the value live without storing it
+          drt_buf_store(obuf, v, lane_boff + (unsigned)j * (unsigned)W * 4u, soff(r));
+        if (GUARD) v = ok ? v : 0.f;
         vmax = fmaxf(vmax, fabsf(v));
         sv[r] = v;
-        sq[r] = v * v;
       }
-      if (p.stats_out && y < H) {   // wave-uniform: GroupNorm partials of this 32-pixel row segment
-        // butterfly over the 32 lanes of a half-wave: at every step a lane keeps half of its registers and receives the
-        // partner's copy of that half, so after 4 steps it owns ONE register summed over 16 lanes and after the 5th over
-        // all 32 (16 shuffles per quantity instead of 5 x 16); the owned register is (l31 >> 1) & 15
-        float a1[8], a2[8];
-        {
-          const bool up = l31 & 16;
+      DRT_PIN_HERE(vmax);      // or the compiler sinks the whole max chain to its only use behind the epilogue, keeping all 128 values alive
+      if (p.stats_out && (!GUARD || y < H)) {   // wave-uniform: GroupNorm partials of this 32-pixel row segment
+        // the two butterflies one after the other (fenced): together their temporaries spill
+        auto butterfly = [&](bool square) -> float {
+          float a[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const float s1 = up ? sv[k] : sv[k + 8], s2 = up ? sq[k] : sq[k + 8];
-            a1[k] = (up ? sv[k + 8] : sv[k]) + __shfl_xor(s1, 16);
-            a2[k] = (up ? sq[k + 8] : sq[k]) + __shfl_xor(s2, 16);
-          }
-        }
-        float b1[4], b2[4];
-        {
-          const bool up = l31 & 8;
+          for (int k = 0; k < 8; ++k)
+            a[k] = square ? drt_xadd<16>(sv[k] * sv[k], sv[k + 8] * sv[k + 8]) : drt_xadd<16>(sv[k], sv[k + 8]);
+          float c[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float s1 = up ? a1[k] : a1[k + 4], s2 = up ? a2[k] : a2[k + 4];
-            b1[k] = (up ? a1[k + 4] : a1[k]) + __shfl_xor(s1, 8);
-            b2[k] = (up ? a2[k + 4] : a2[k]) + __shfl_xor(s2, 8);
-          }
-        }
-        float c1[2], c2[2];
-        {
-          const bool up = l31 & 4;
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const float s1 = up ? b1[k] : b1[k + 2], s2 = up ? b2[k] : b2[k + 2];
-            c1[k] = (up ? b1[k + 2] : b1[k]) + __shfl_xor(s1, 4);
-            c2[k] = (up ? b2[k + 2] : b2[k]) + __shfl_xor(s2, 4);
-          }
-        }
-        float d1, d2;
-        {
-          const bool up = l31 & 2;
-          const float s1 = up ? c1[0] : c1[1], s2 = up ? c2[0] : c2[1];
-          d1 = (up ? c1[1] : c1[0]) + __shfl_xor(s1, 2);
-          d2 = (up ? c2[1] : c2[0]) + __shfl_xor(s2, 2);
-        }
-        d1 += __shfl_xor(d1, 1);
-        d2 += __shfl_xor(d2, 1);
-        const int r = (l31 >> 1) & 15;
-        const int co = co_base + (r & 3) + 8 * (r >> 2);
-        if ((l31 & 1) == 0 && co < p.Cout) {
+          for (int k = 0; k < 4; ++k) c[k] = drt_xadd<8>(a[k], a[k + 4]);
+          const float d0 = drt_xadd<7>(c[0], c[2]), d1 = drt_xadd<7>(c[1], c[3]);
+          return drt_add_xor2(drt_xadd<1>(d0, d1));
+        };
+        // squares first: the exchange instructions overwrite their operands, and the second pass may then consume sv itself
+        const float e2 = butterfly(true);
+        __builtin_amdgcn_sched_barrier(0);
+        const float e1 = butterfly(false);
+        // the register this lane ended up with: bit 3 of r from lane bit 4, bit 2 from bit 3, bit 1 from bit 2, bit 0 from bit 0
+        const int r = ((l31 >> 4) & 1) * 8 + ((l31 >> 3) & 1) * 4 + ((l31 >> 2) & 1) * 2 + (l31 & 1);
+        const int co = co_l + (r & 3) + 8 * (r >> 2);
+        // lanes l and l ^ 2 hold the same sums and both store them (same address, same value): predicating one of them
+        // away costs an exec-mask region per row, which the compiler gathers at the end of the epilogue with the sums spilled
+        if (!GUARD || co < p.Cout) {
           float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)y * tiles_x + tx) * 2;
-          so[0] = d1; so[1] = d2;
+          so[0] = e1; so[1] = e2;
         }
       }
     }
+  }
+  // four instantiations of this body meet behind the dispatch below: without a marker that differs per instantiation the
+  // compiler sinks their (identical) tails into the common successor and carries every operand there in a phi (spills)
+  DRT_CODE_MARKER(GUARD * 2 + RES);
+  return vmax;
+}
+
+// ABL (measurement-only instantiations of sgmse_bench_conv; results are then WRONG on purpose): bit 0 skip the global
+// stores, bit 1 skip the residual read
+// PRE: the kernel initialised its accumulators with (bias + bias2) / as (conv_acc_init), the epilogue adds no bias
+template <class T, int FC, int FP, int WC, int ABL = 0, bool PRE = false>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[FC][FP], int b, int co_blk, int tx, int ty,
+                                              int tiles_x, int wc, int wp, int l31, int kh, float as_mul = 1.0f) {
+  const float as = (p.acc_scale ? *p.acc_scale : 1.0f) * as_mul;     // exact powers of two (or 1)
+  // wave-uniform: are this wave's channels, rows and columns all inside the tensor?
+  const bool inside = (co_blk * T::CO_T + (wc * FC + FC) * 32 <= p.Cout) && (ty * T::ROWS + wp * FP + FP <= p.H) && (tx * 32 + 32 <= p.W);
+  const bool res = p.res != nullptr && !(ABL & 2);
+  float vmax;
+  if (inside) {
+    if (res) vmax = conv_epilogue_body<T, FC, FP, WC, false, ABL, PRE, true>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
+    else vmax = conv_epilogue_body<T, FC, FP, WC, false, ABL, PRE, false>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
+  } else {
+    if (res) vmax = conv_epilogue_body<T, FC, FP, WC, true, ABL, PRE, true>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
+    else vmax = conv_epilogue_body<T, FC, FP, WC, true, ABL, PRE, false>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
   }
   if (p.amax_out) {      // wave-uniform
 #pragma unroll

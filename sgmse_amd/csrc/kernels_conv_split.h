@@ -57,6 +57,13 @@ struct SplitB3 {
     const float r2 = r1 - __builtin_bit_cast(float, mid);
     t[0] = hi >> 16; t[1] = mid >> 16; t[2] = __builtin_bit_cast(uint32_t, r2) >> 16;
   }
+  // two consecutive K-elements -> one dword per split term (element 0 in the low half)
+  __device__ static __forceinline__ void split2(float x0, float x1, uint32_t (&d)[3]) {
+    uint32_t a[3], b[3];
+    split(x0, a); split(x1, b);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) d[s] = a[s] | (b[s] << 16);
+  }
   __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) { return mfma_32x32x16_bf16(a, b, c); }
 };
 
@@ -71,6 +78,12 @@ struct SplitH2 {
     const uint32_t hi = drt_f32_to_f16(x);
     const float r = x - drt_f16_to_f32(hi);
     t[0] = hi; t[1] = drt_f32_to_f16(r);
+  }
+  // two consecutive K-elements -> {hi pair, lo pair}: two packed round-to-nearest conversions (v_cvt_pk_f16_f32)
+  __device__ static __forceinline__ void split2(float x0, float x1, uint32_t (&d)[2]) {
+    const uint32_t hi = drt_f32x2_to_f16x2(x0, x1);
+    const float r0 = x0 - drt_f16_to_f32(hi & 0xffffu), r1 = x1 - drt_f16_to_f32(hi >> 16);
+    d[0] = hi; d[1] = drt_f32x2_to_f16x2(r0, r1);
   }
   __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) { return mfma_32x32x16_f16(a, b, c); }
 };
@@ -157,7 +170,22 @@ inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<
 //            are bound by the producer arithmetic and HBM, not by the matrix pipe.
 //   SHAPE 2: as 0 with 4 rows (128 co x 4 rows x 32 px): twice the workgroups of half the duration, for launches that
 //            cannot fill the chip (small batches: the per-file loop of enhancement.py).
-template <class S, int SHAPE = 0>
+// ACT: the fused producer applies SiLU after the affine (1) or only the affine (0: raw / FIR-resampled inputs, scale 1).
+//
+// Fused producer, per staged element (the VALU work of this kernel: it runs beside the MFMA stream and its instruction
+// count sets the power the matrix pipe is left with):
+//     t  = x * s + h            s, h: GroupNorm scale/shift of the channel, pre-multiplied by the fp16x2 input scale 2^4
+//     u  = x * s2 + h2          s2, h2 = -log2(e) * (s, h) / 2^4: the exponent of exp(-t) without a dependent multiply
+//     o  = t / (1 + 2^u)        v_exp_f32, v_add, v_rcp_f32, v_mul
+//     o  = clamp(o, +-65504)    (cannot bind for GroupNorm outputs, see the engine's guard; keeps the conversion finite)
+//     hi = f16(o), lo = f16(o - hi) for two elements at a time (v_cvt_pk_f16_f32)
+// The four coefficients of a channel are one 16-byte LDS read.  Zero padding: a staged item outside the image never
+// changes, so its LDS slots are written once (zeros) and its per-stage stores go to a dummy slot behind the tile.
+//
+// ABL: measurement-only instantiations reachable from sgmse_bench_conv (profiles/r02_split_ablation.txt), results WRONG on
+// purpose: 1 no epilogue stores, 2 no residual read, 4 producer without the transcendental pair, 8 nothing staged after
+// the first K-stage (no raw loads, producer, LDS writes), 16 B fragments read from LDS once, 32 A fragments loaded once.
+template <class S, int SHAPE = 0, int ACT = 1, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   constexpr bool THIN = SHAPE == 1;
   constexpr int ROWS = SHAPE == 2 ? 4 : 8;
@@ -169,10 +197,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   constexpr int FPW = THIN ? 2 : ROWS;     // pixel fragments per wave
   constexpr int EPJ = 8 / FPW;             // producer elements staged behind each fragment's MFMAs
   constexpr int STAGE_V = C::TROWS * C::TCOLS * PX_V;
-  __shared__ u32x4 s_in0[STAGE_V];
-  __shared__ u32x4 s_in1[STAGE_V];
-  __shared__ float s_sc[512];
-  __shared__ float s_sh[512];
+  constexpr int DUMMY_V = STAGE_V;         // scratch slot behind the tile for the stores of items outside the image
+  __shared__ u32x4 s_in0[STAGE_V + NS];
+  __shared__ u32x4 s_in1[STAGE_V + NS];
+  // per input channel {s, h, s2, h2}; the bf16x3 policy keeps {s, h} only (its three split terms per element leave no LDS
+  // for the wider table at two workgroups per CU) and derives the exponent with a dependent multiply
+  constexpr int NCO = S::SCALED ? 4 : 2;
+  __shared__ float s_co[512 * NCO];
 
   const int tid = threadIdx.x;
   const int Cin = p.C1 + p.C2;
@@ -185,20 +216,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   const int b = bid / tiles_y;
   const int co_blk = blockIdx.y;
   const int x0 = tx * 32, y0 = ty * ROWS;
-  const bool xform = p.in_scale != nullptr;
-  for (int c = tid; c < Cin; c += 256) {
-    s_sc[c] = xform ? p.in_scale[b * Cin + c] : 1.f;
-    s_sh[c] = xform ? p.in_shift[b * Cin + c] : 0.f;
+  {
+    const bool xform = p.in_scale != nullptr;
+    constexpr float kx = S::SCALED ? kH2XScale : 1.f;
+    constexpr float nl2e = -1.4426950408889634f;
+    for (int c = tid; c < Cin; c += 256) {
+      const float sc = xform ? p.in_scale[b * Cin + c] : 1.f, sh = xform ? p.in_shift[b * Cin + c] : 0.f;
+      if constexpr (NCO == 4) {
+        f32x4 v;
+        v[0] = sc * kx; v[1] = sh * kx; v[2] = sc * nl2e; v[3] = sh * nl2e;
+        reinterpret_cast<f32x4*>(s_co)[c] = v;
+      } else {
+        s_co[2 * c] = sc * kx; s_co[2 * c + 1] = sh * kx;
+      }
+    }
   }
-  const float actf = (xform && p.in_act) ? 1.f : 0.f;   // arithmetic blend below: a branch would split the MFMA loop body
-  const size_t HW = (size_t)H * W;
+  const unsigned HW = (unsigned)H * (unsigned)W;
 
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
 
   // staging items of this thread: (k-group g, tile row r, tile column c), c fastest so that a wave's loads of one
   // channel are consecutive pixels.  Items past the end repeat the last one (same address, same value).
-  int it_goff[C::NIT], it_loff[C::NIT], it_g[C::NIT];
-  unsigned okmask = 0;
+  unsigned it_boff[C::NIT];                // byte offset of (channel 8 g, pixel) inside a 16-channel slab of the source
+  int it_loff[C::NIT], it_g[C::NIT];
 #pragma unroll
   for (int i = 0; i < C::NIT; ++i) {
     int it = tid + 256 * i;
@@ -208,79 +248,96 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     const int r = rem / C::TCOLS, c = rem - r * C::TCOLS;
     const int gy = y0 - 1 + r, gx = x0 - 1 + c;
     const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    okmask |= (ok ? 1u : 0u) << i;
-    it_goff[i] = ok ? gy * W + gx : 0;
-    it_loff[i] = (r * C::TCOLS + c) * PX_V + g * NS;     // in u32x4 units
+    const int loff = (r * C::TCOLS + c) * PX_V + g * NS;     // in u32x4 units
+    if (!ok) {                                                // zero padding applies to the producer's OUTPUT: written once
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { s_in0[loff + s] = u32x4{0u, 0u, 0u, 0u}; s_in1[loff + s] = u32x4{0u, 0u, 0u, 0u}; }
+    }
+    it_boff[i] = ((unsigned)(8 * g) * HW + (ok ? (unsigned)(gy * W + gx) : 0u)) * 4u;
+    it_loff[i] = ok ? loff : DUMMY_V;
     it_g[i] = g;
   }
 
   float rin[C::NIT][8];
   auto load_item = [&](int i, int c0) {    // raw global loads of one staged item of stage c0 (consumed >= 3 taps later)
     const bool first = c0 < p.C1;
+    // uniform slab pointer + 32-bit lane offset: global_load with an SGPR base, no per-load address arithmetic
     const float* base = first ? p.src1 + ((size_t)b * p.C1 + c0) * HW : p.src2 + ((size_t)b * p.C2 + (c0 - p.C1)) * HW;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) rin[i][e] = base[(size_t)(8 * it_g[i] + e) * HW + it_goff[i]];
+    for (int e = 0; e < 8; ++e)
+      rin[i][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (size_t)e * HW) + it_boff[i]);
   };
-  auto store_item = [&](int i, int c0, u32x4* sbuf) {   // producer + split + LDS write of one staged item
-    uint32_t t16[8][NS];
-    const bool ok = (okmask >> i) & 1u;
+  // producer of one element -> the value that is split (already scaled)
+  auto produce = [&](float x, int ch) -> float {
+    float o, u;
+    if constexpr (NCO == 4) {
+      const f32x4 co = reinterpret_cast<const f32x4*>(s_co)[ch];
+      o = x * co[0] + co[1];
+      u = x * co[2] + co[3];
+    } else {
+      o = x * s_co[2 * ch] + s_co[2 * ch + 1];
+      u = o * -1.4426950408889634f;
+    }
+    if constexpr (ACT == 1) {
+      if constexpr (ABL & 4) o = o * u;
+      else o = o * __builtin_amdgcn_rcpf(1.0f + drt_exp2(u));       // SiLU: t * sigmoid(t)
+    }
+    if (S::SCALED) o = fminf(fmaxf(o, -65504.f), 65504.f);
+    return o;
+  };
+  auto store_item = [&](int i, int c0, u32x4* sbuf) {   // producer + split + LDS write of one staged item (prologue)
+    u32x4 v[NS];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int ch = c0 + 8 * it_g[i] + e;
-      float t = rin[i][e] * s_sc[ch] + s_sh[ch];
-      const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-      t *= actf * (sig - 1.0f) + 1.0f;      // SiLU when actf = 1, identity when 0
-      t = ok ? t : 0.f;                     // zero padding applies to the producer's OUTPUT
-      if (S::SCALED) t = fminf(fmaxf(t * kH2XScale, -65504.f), 65504.f);
-      S::split(t, t16[e]);
+    for (int q = 0; q < 4; ++q) {
+      const int ch = c0 + 8 * it_g[i] + 2 * q;
+      uint32_t d[NS];
+      S::split2(produce(rin[i][2 * q], ch), produce(rin[i][2 * q + 1], ch + 1), d);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) v[s][q] = d[s];
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      u32x4 v;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = t16[2 * q][s] | (t16[2 * q + 1][s] << 16);
-      sbuf[it_loff[i] + s] = v;
-    }
+    for (int s = 0; s < NS; ++s) sbuf[it_loff[i] + s] = v[s];
   };
 
-  // the same, one ELEMENT at a time: the eight elements of an item are spread over the eight pixel fragments of a tap
-  // (one per fragment, behind that fragment's MFMAs and inside its scheduling fences), so that the producer arithmetic
-  // issues while the MFMA pipe works instead of after the tap
+  // the same, one ELEMENT at a time: the eight elements of an item are spread over the pixel fragments of a tap (behind
+  // a fragment's MFMAs and inside its scheduling fences), so that the producer arithmetic issues while the MFMA pipe
+  // works instead of after the tap; the split runs on every second element (packed conversions)
   u32x4 pk[NS];
-  uint32_t ev[NS];
+  float ev = 0.f;
   auto stage_elem = [&](int i, int e, int c0) {
-    const bool ok = (okmask >> i) & 1u;
-    const int ch = c0 + 8 * it_g[i] + e;
-    float t = rin[i][e] * s_sc[ch] + s_sh[ch];
-    const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-    t *= actf * (sig - 1.0f) + 1.0f;
-    t = ok ? t : 0.f;
-    if (S::SCALED) t = fminf(fmaxf(t * kH2XScale, -65504.f), 65504.f);
-    uint32_t t16[NS];
-    S::split(t, t16);
+    const float o = produce(rin[i][e], c0 + 8 * it_g[i] + e);
+    if ((e & 1) == 0) { ev = o; return; }
+    uint32_t d[NS];
+    S::split2(ev, o, d);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if ((e & 1) == 0) ev[s] = t16[s]; else pk[s][e >> 1] = ev[s] | (t16[s] << 16);
-    }
+    for (int s = 0; s < NS; ++s) pk[s][e >> 1] = d[s];
   };
   auto flush_item = [&](int i, u32x4* sbuf) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) sbuf[it_loff[i] + s] = pk[s];
   };
 
+  // accumulators start from (bias + time-embedding row) / acc_scale (conv_acc_init): no bias work in the epilogue
   f32x16 acc[1][FPW];
+  {
+    float init[16];
+    conv_acc_init<T>(p, b, co_blk, THIN ? 0 : wave, kg, 1.0f, init);
 #pragma unroll
-  for (int j = 0; j < FPW; ++j)
+    for (int j = 0; j < FPW; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[0][j][r] = init[r];
+  }
 
   const int nst = Cin / C::KC;
-  // A fragments of this wave: [co_blk][stage][tap][split][wave][lane] (THIN: every wave uses fragment 0)
-  const u32x4* wbase = reinterpret_cast<const u32x4*>(p.w) + (size_t)co_blk * nst * 9 * NS * 4 * 64 + (THIN ? 0 : wave) * 64 + lane;
+  // A fragments of this wave: [co_blk][stage][tap][split][wave][lane] (THIN: every wave uses fragment 0); uniform
+  // fragment pointer + lane byte offset
+  const u32x4* wblk = reinterpret_cast<const u32x4*>(p.w) + (size_t)co_blk * nst * 9 * NS * 4 * 64;
+  const unsigned a_boff = (unsigned)(((THIN ? 0 : wave) * 64 + lane) * 16);
   auto load_a = [&](int st, int tap, u32x4 (&a)[NS]) {
-    const u32x4* q = wbase + ((size_t)st * 9 + tap) * NS * 4 * 64;
+    const u32x4* q = wblk + (size_t)(st * 9 + tap) * NS * 4 * 64;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) a[s] = q[s * 4 * 64];
+    for (int s = 0; s < NS; ++s)
+      a[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s * 4 * 64) + a_boff);
   };
   // B fragment base of this lane inside a stage buffer (u32x4 units): pixel (row j + dy, col l31 + dx), k-group kg
   const int b_lane = l31 * PX_V + kg * NS + (THIN ? wave * FPW * C::TCOLS * PX_V : 0);
@@ -288,18 +345,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   // one tap of one stage: FPW pixel fragments x NP split products.  The B reads of fragment j+1 are issued before the
   // MFMAs of fragment j (order pinned with sched_barrier: left alone, the compiler sinks every LDS read to just in front
   // of its first use and waits lgkmcnt(0) for each).
+  u32x4 bq[2][NS];
   auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[NS], int item, int c0n, u32x4* nxt) {
     const int dy = tap / 3, dx = tap - 3 * dy;
     const u32x4* sb = sbuf + b_lane + (dy * C::TCOLS + dx) * PX_V;
-    u32x4 bq[2][NS];
+    if constexpr (!(ABL & 16)) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) bq[0][s] = sb[s];
+      for (int s = 0; s < NS; ++s) bq[0][s] = sb[s];
+    }
 #pragma unroll
     for (int j = 0; j < FPW; ++j) {
-      if (j + 1 < FPW) {
-        const u32x4* q = sb + (j + 1) * C::TCOLS * PX_V;
+      if constexpr (!(ABL & 16)) {
+        if (j + 1 < FPW) {
+          const u32x4* q = sb + (j + 1) * C::TCOLS * PX_V;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) bq[(j + 1) & 1][s] = q[s];
+          for (int s = 0; s < NS; ++s) bq[(j + 1) & 1][s] = q[s];
+        }
       }
       __builtin_amdgcn_sched_barrier(SGMSE_SPLIT_FENCE);
       f32x16 c = acc[0][j];
@@ -318,13 +379,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   // prologue: stage 0 -> s_in0
 #pragma unroll
   for (int i = 0; i < C::NIT; ++i) load_item(i, 0);
-  __syncthreads();          // s_sc / s_sh visible
+  __syncthreads();          // s_co and the zero padding visible
 #pragma unroll
   for (int i = 0; i < C::NIT; ++i) store_item(i, 0, s_in0);
   __syncthreads();
 
   u32x4 a0[NS], a1[NS];
   load_a(0, 0, a0);
+  if constexpr (ABL & 16) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { bq[0][s] = s_in0[b_lane + s]; bq[1][s] = s_in0[b_lane + C::TCOLS * PX_V + s]; }
+  }
+  if constexpr (ABL & 32) load_a(0, 1, a1);
 #pragma unroll 1
   for (int st = 0; st < nst; ++st) {
     // the stage after this one, clamped: the last stage re-stages itself into the buffer nobody reads again, which
@@ -339,20 +405,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     for (int tap = 0; tap < 9; ++tap) {
       const int ntap = tap + 1 < 9 ? tap + 1 : 0;
       const int nstg = tap + 1 < 9 ? st : stn;
-      if (tap & 1) load_a(nstg, ntap, a0); else load_a(nstg, ntap, a1);
-      if (tap < C::NIT) load_item(tap, stn * C::KC);
+      if constexpr (!(ABL & 32)) { if (tap & 1) load_a(nstg, ntap, a0); else load_a(nstg, ntap, a1); }
+      if constexpr (!(ABL & 8)) { if (tap < C::NIT) load_item(tap, stn * C::KC); }
       __builtin_amdgcn_sched_barrier(0);
-      const int item = (tap >= 4 && (tap & 1) == 0 && (tap - 4) / 2 < C::NIT) ? (tap - 4) / 2 : -1;   // taps 4, 6, 8: items 0, 1, 2
+      int item = (tap >= 4 && (tap & 1) == 0 && (tap - 4) / 2 < C::NIT) ? (tap - 4) / 2 : -1;   // taps 4, 6, 8: items 0, 1, 2
+      if constexpr (ABL & 8) item = -1;
       if (tap & 1) compute_tap(cur, tap, a1, item, stn * C::KC, nxt); else compute_tap(cur, tap, a0, item, stn * C::KC, nxt);
     }
     __syncthreads();
     // nine taps: the register sets have swapped roles (tap 8 computed from a0 and prefetched the next stage into a1)
+    if constexpr (!(ABL & 32)) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) a0[s] = a1[s];
+      for (int s = 0; s < NS; ++s) a0[s] = a1[s];
+    }
   }
 
-  if constexpr (THIN) conv_epilogue<T, 1, FPW, 1>(p, acc, b, co_blk, tx, ty, tiles_x, 0, wave, l31, kg);
-  else conv_epilogue<T, 1, FPW, 4>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);
+  if constexpr (THIN) conv_epilogue<T, 1, FPW, 1, ABL & 3, true>(p, acc, b, co_blk, tx, ty, tiles_x, 0, wave, l31, kg);
+  else conv_epilogue<T, 1, FPW, 4, ABL & 3, true>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -29,11 +29,61 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_f16(u32x4 a, u32x4 b, f32x16 c) 
 // fp32 <-> fp16 bit patterns (round to nearest even, hardware conversion)
 __device__ __forceinline__ uint32_t drt_f32_to_f16(float x) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)x); }
 __device__ __forceinline__ float drt_f16_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
+// two fp32 -> packed fp16 pair (element 0 in the low half), round to nearest even: v_cvt_pk_f16_f32
+__device__ __forceinline__ uint32_t drt_f32x2_to_f16x2(float x0, float x1) {
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  const f2_t v = {x0, x1};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2_t));
+}
+__device__ __forceinline__ float drt_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+// Raw buffer view of a global fp32 tensor slice: address = base + voff (per-lane VGPR, bytes) + soff (uniform SGPR, bytes).
+// One buffer_load/store_dword per access with NO address arithmetic on the vector ALU; offsets must stay below 2^31.
+struct drt_buf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ drt_buf drt_make_buf(const float* base) {
+  return drt_buf{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000)};
+}
+__device__ __forceinline__ float drt_buf_load(const drt_buf& b, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
+}
+__device__ __forceinline__ void drt_buf_store(const drt_buf& b, float v, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, voff, soff, 0);
+}
 // atomic max of non-negative floats (their bit patterns order like unsigned integers)
 __device__ __forceinline__ void drt_atomic_max_nonneg(float* p, float v) {
   atomicMax(reinterpret_cast<unsigned int*>(p), __builtin_bit_cast(unsigned int, v));
 }
 
+// Exchange-add steps of the GroupNorm-statistics butterfly over the 32 lanes that hold one 32-pixel row segment (both
+// 32-lane halves of a wave do the same thing).  drt_xadd<P>(a, b): a lane whose selector bit is 0 returns a + a', the others
+// b + b', where x' is the value of x in the partner lane:
+//   P = 16: partner lane ^ 16, selector bit 4   (v_permlane16_swap_b32: one swap + one add)
+//   P = 8 : partner lane ^ 8,  selector bit 3   (DPP row_ror:8)
+//   P = 7 : partner lane ^ 7 (mirror inside a group of 8), selector bit 2   (DPP row_half_mirror)
+//   P = 1 : partner lane ^ 1,  selector bit 0   (DPP quad_perm [1,0,3,2])
+// drt_add_xor2(a) = a + a' with partner lane ^ 2 (DPP quad_perm [2,3,0,1]).  No LDS-pipe traffic (ds_bpermute) anywhere.
+template <int CTRL>
+__device__ __forceinline__ float drt_dpp_add(float a) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), CTRL, 0xf, 0xf, true);
+  return a + __builtin_bit_cast(float, t);
+}
+template <int P>
+__device__ __forceinline__ float drt_xadd(float a, float b) {
+  if constexpr (P == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];      // (bit_cast of r[i] directly reads element 0 twice with this clang)
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+  } else {
+    constexpr int ctrl = P == 8 ? 0x128 : P == 7 ? 0x141 : 0xB1;
+    constexpr unsigned bit = P == 8 ? 8u : P == 7 ? 4u : 1u;
+    const float t = drt_dpp_add<ctrl>(a), u = drt_dpp_add<ctrl>(b);
+    return (threadIdx.x & bit) ? u : t;
+  }
+}
+__device__ __forceinline__ float drt_add_xor2(float a) { return drt_dpp_add<0x4E>(a); }
+
+#define DRT_PIN_HERE(x) asm volatile("" : "+v"(x))
+#define DRT_CODE_MARKER(n) asm volatile("; code marker %0" ::"n"(n))
 #define DRT_LAUNCH(kern, grid, block, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)
 

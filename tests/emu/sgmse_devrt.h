@@ -62,12 +62,27 @@ static inline f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) { return emu
 static inline f32x16 mfma_32x32x16_f16(u32x4 a, u32x4 b, f32x16 c) { return emu::mfma_32x32x16_f16(a, b, c); }
 static inline uint32_t drt_f32_to_f16(float x) { return emu::f32_to_f16(x); }
 static inline float drt_f16_to_f32(uint32_t h) { return emu::f16_to_f32(h); }
+struct drt_buf { char* p; };
+static inline drt_buf drt_make_buf(const float* base) { return drt_buf{reinterpret_cast<char*>(const_cast<float*>(base))}; }
+static inline float drt_buf_load(const drt_buf& b, unsigned voff, unsigned soff) { float v; memcpy(&v, b.p + voff + soff, 4); return v; }
+static inline void drt_buf_store(const drt_buf& b, float v, unsigned voff, unsigned soff) { memcpy(b.p + voff + soff, &v, 4); }
+static inline uint32_t drt_f32x2_to_f16x2(float x0, float x1) { return emu::f32_to_f16(x0) | (emu::f32_to_f16(x1) << 16); }
+static inline float drt_exp2(float x) { return exp2f(x); }
 static inline void drt_atomic_max_nonneg(float* p, float v) {
   uint32_t* ip = reinterpret_cast<uint32_t*>(p);
   uint32_t nv; memcpy(&nv, &v, 4);
   uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED);
   while (old < nv && !__atomic_compare_exchange_n(ip, &old, nv, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 }
+// exchange-add steps of the GroupNorm butterfly (see sgmse_amd/csrc/sgmse_devrt.h)
+template <int P>
+static inline float drt_xadd(float a, float b) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int bit = P == 16 ? 16 : P == 8 ? 8 : P == 7 ? 4 : 1;
+  const float ap = emu::shfl_idx(a, lane ^ P), bp = emu::shfl_idx(b, lane ^ P);
+  return (lane & bit) ? b + bp : a + ap;
+}
+static inline float drt_add_xor2(float a) { return a + emu::shfl_xor(a, 2); }
 static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) { return emu::mfma_16x16x4(a, b, c); }
 #define __builtin_amdgcn_iglp_opt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
@@ -88,6 +103,8 @@ static inline float atomicAdd(float* p, float v) {
 }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
+#define DRT_PIN_HERE(x) ((void)0)
+#define DRT_CODE_MARKER(n) ((void)0)
 #define DRT_LAUNCH(kern, grid, block, stream, ...) \
   do { (void)(stream); emu::launch((grid), (block), [=]() { kern(__VA_ARGS__); }); } while (0)
 

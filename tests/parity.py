@@ -326,6 +326,55 @@ def check_enhance(dev, L=8000, N=2):
     assert nfe == 2 * N and rel_l2(xb[0].cpu(), x_ref) < WAVE_TOL
 
 
+def check_full_config(dev, name):
+    """A BASELINE.json configuration itself, one utterance, against the REFERENCE's own output (fixture written by
+    oracle/make_golden_full.py from the reference's full-width network, OUVESDE and pc_sampler with replayed noise):
+    full-width network x full utterance x full N, through the batched entry point; gates: sampled spectrogram <= 1e-4,
+    enhanced waveform <= 1e-3 (north star).  Inputs are rebuilt from seeds (oracle/full_cases.py)."""
+    from oracle.full_cases import FULL_CASES, front_cfg
+    c = FULL_CASES[name]
+    z = load(name)
+    cfg = NO.NetCfg.for_variant(c["variant"])
+    fc = front_cfg(c["front"])
+    m, _ = make_model(cfg, dev, P=synth.synth_params(cfg, seed=c["param_seed"]), N=c["N"], n_fft=fc.n_fft, hop_length=fc.hop_length,
+                      spec_factor=fc.spec_factor, spec_abs_exponent=fc.spec_abs_exponent, **c["sde"])
+    y = synth.synth_waveform(c["L"], seed=c["wave_seed"], batch=1)
+    frames = c["L"] // fc.hop_length + 1
+    T = (frames + 63) // 64 * 64
+    ndraws = 1 + (2 * c["N"] if c["sampler"] == "pc" else 0)
+    noise = replay_noise((1, 1, fc.n_fft // 2 + 1, T), ndraws, seed=c["noise_seed"]).to(dev)
+    got = {}
+    orig = m.get_pc_sampler if c["sampler"] == "pc" else m.get_ode_sampler
+
+    def spy(*a, **k):                       # keep the sampled spectrogram of the run below
+        s = orig(*a, **k)
+        def run():
+            got["spec"], got["nfe"] = s()
+            return got["spec"], got["nfe"]
+        return run
+    setattr(m, "get_pc_sampler" if c["sampler"] == "pc" else "get_ode_sampler", spy)
+    x_hat, nfe = m.enhance_batch(y.to(dev), N=c["N"], snr=c["snr"], sampler_type=c["sampler"], noise=noise, pad_mode=c["pad"])
+    e_spec, e_wave = rel_l2(got["spec"].cpu(), z["spec"]), rel_l2(x_hat[0].cpu(), z["wave"])
+    print(f"{name} on {dev}: {nfe} NFE, rel_l2 vs the reference: spectrogram {e_spec:.3e}, waveform {e_wave:.3e}")
+    assert nfe == int(z["nfe"]) and got["spec"].shape == z["spec"].shape
+    assert e_spec < SAMPLER_TOL and e_wave < WAVE_TOL, (name, e_spec, e_wave)
+
+
+def check_batch_equals_singles(dev, B=4):
+    """enhance_batch over B utterances equals the B single-utterance runs bit for bit (full-width network, 4 s, replayed
+    noise; short N to bound the run time): utterances never interact and no kernel choice depends on the batch size in a
+    way that changes a bit."""
+    cfg = NO.NetCfg.for_variant("ncsnpp")
+    m, _ = make_model(cfg, dev)
+    y = synth.synth_waveform(64000, seed=3, batch=B)
+    N = 2
+    noise = replay_noise((B, 1, 256, 512), 1 + 2 * N).to(dev)
+    full, _ = m.enhance_batch(y.to(dev), N=N, noise=noise)
+    for i in range(B):
+        one, _ = m.enhance_batch(y[i:i + 1].to(dev), N=N, noise=noise[:, i:i + 1].contiguous())
+        assert torch.equal(one[0], full[i]), i
+
+
 def check_sampler_oracle(dev, variant="ncsnpp_48k", N=2, corrector="ald", snr=0.33, F_=192, T=64, B=1, use_graph=True):
     """PC sampler of a reduced-width model against the oracle loop with replayed noise (covers ncsnpp_48k, whose
     output_layer / division-by-t order differs: ncsnpp_48k.py:414-421)."""

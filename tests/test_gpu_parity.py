@@ -297,6 +297,17 @@ def test_full_width_48k_forward_against_oracle(hip):
     assert rel_l2(out.cpu(), ref) < P.NET_TOL
 
 
+@pytest.mark.parametrize("name", ["pc16k_full", "ode16k_full", "pc48k_full"])
+def test_baseline_configuration_end_to_end_against_the_reference(hip, name):
+    """BASELINE.json configs[0]/[1] (PC N=30), configs[2] (PF-ODE N=30) and configs[3] (48 kHz, PC N=50) at full width,
+    full length and full N: sampled spectrogram and enhanced waveform vs the reference's own run (tests/golden/*_full.npz)."""
+    P.check_full_config(hip, name)
+
+
+def test_batch_of_four_equals_four_singles_bitwise(hip):
+    P.check_batch_equals_singles(hip, 4)
+
+
 def test_full_size_batch_independence(hip):
     """Size-independent property at the bench shape: utterances never interact, so a batched evaluation equals the
     per-utterance evaluations bit for bit, in any batch position."""
