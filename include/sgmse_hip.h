@@ -161,6 +161,9 @@ int sgmse_profile_forward(sgmse_ctx* ctx, const void* xy, const float* t, void* 
 int sgmse_bench_conv(sgmse_ctx* ctx, int ks, int B, int Cin, int Cout, int H, int W, int variant, int iters, int fused,
                      float* ms);
 int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out);
+/* how many times this context captured + instantiated a sampler step as a hipGraph (a run over many batches of one shape and
+ * sampler configuration captures once: the Philox seed is device data, not a graph parameter) */
+int sgmse_graph_captures(sgmse_ctx* ctx, int* out);
 
 #ifdef __cplusplus
 }

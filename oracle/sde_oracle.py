@@ -150,7 +150,9 @@ def pc_sample(sde: OUVE, score: Callable, y: torch.Tensor, noise: Callable, *, e
                 xt, xm = revdiff_update(sde, score, xt, y, vec_t, stepsize, noise, probability_flow)
             elif predictor == "euler_maruyama":
                 xt, xm = euler_maruyama_update(sde, score, xt, y, vec_t, noise)
-            elif predictor != "none":
+            elif predictor == "none":
+                xm = xt                                                # NonePredictor.update_fn returns (x, x), predictors.py:69-76
+            else:
                 raise ValueError(predictor)
             if trace is not None:
                 trace.append(xt.clone())

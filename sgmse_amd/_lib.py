@@ -69,6 +69,7 @@ _SIGS = {
     "sgmse_profile_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(_I)]),
     "sgmse_bench_conv": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "sgmse_arena_bytes": (_I, [_P, C.POINTER(_LL)]),
+    "sgmse_graph_captures": (_I, [_P, C.POINTER(_I)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -361,6 +362,12 @@ class Context:
         """0: fp32 MFMA, 1: bf16x3 split, 2: fp16x2 split on the wide 3x3 layers (kernels_conv_split.h)."""
         out = C.c_int(0)
         self.check(self.lib.sgmse_conv_split_mode(self.h, C.byref(out)))
+        return out.value
+
+    def graph_captures(self) -> int:
+        """Number of hipGraph captures (+ instantiations) of a sampler step this context has done."""
+        out = _I(0)
+        self.check(self.lib.sgmse_graph_captures(self.h, C.byref(out)))
         return out.value
 
     def arena_bytes(self) -> int:

@@ -200,4 +200,9 @@ int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out) {
   return sg_guard(ctx, [&](sgmse::Engine& e) { *out = (long long)e.arena_bytes(); });
 }
 
+int sgmse_graph_captures(sgmse_ctx* ctx, int* out) {
+  SG_ARG(ctx, out != nullptr, "out is null");
+  return sg_guard(ctx, [&](sgmse::Engine& e) { *out = e.graph_captures(); });
+}
+
 }  // extern "C"

@@ -8,6 +8,9 @@
 #ifndef SGMSE_CONV_SPLIT_DEFAULT
 #define SGMSE_CONV_SPLIT_DEFAULT 2     // 0: fp32 MFMA everywhere, 1: bf16x3 on the wide levels, 2: fp16x2 on the wide levels
 #endif
+#ifndef SGMSE_SPLIT_STAGGER_DEFAULT
+#define SGMSE_SPLIT_STAGGER_DEFAULT 0  // cycles per K-stage by which the first residency round of the split 3x3 kernel is de-phased (0: off)
+#endif
 #ifndef SGMSE_CONV_PIPE_DEFAULT
 #define SGMSE_CONV_PIPE_DEFAULT 1
 #endif
@@ -112,6 +115,7 @@ inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t
   if (abl && mode == 2) {
 #define SGMSE_ABL_CASE(V) if (abl == V) { DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 0, 1, V>), grid, dim3(256), st, a); return; }
     SGMSE_ABL_CASE(3) SGMSE_ABL_CASE(4) SGMSE_ABL_CASE(8) SGMSE_ABL_CASE(24) SGMSE_ABL_CASE(56) SGMSE_ABL_CASE(59)
+    SGMSE_ABL_CASE(1) SGMSE_ABL_CASE(2) SGMSE_ABL_CASE(64) SGMSE_ABL_CASE(67) SGMSE_ABL_CASE(72) SGMSE_ABL_CASE(128) SGMSE_ABL_CASE(256) SGMSE_ABL_CASE(512)
 #undef SGMSE_ABL_CASE
   }
   if (mode == 2) launch_conv3x3_split_t<SplitH2, 0>(a, grid, st); else launch_conv3x3_split_t<SplitB3, 0>(a, grid, st);

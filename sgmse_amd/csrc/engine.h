@@ -407,7 +407,7 @@ class Engine {
     SG_CHECK(drt::memcpy_d2d(sy_, Y, n * 8, stream_));   // engine-owned copy: the captured graph never refers to caller memory
     Y = sy_;
     SamplerArgs sa{};
-    sa.x = sx_; sa.x_mean = sxm_; sa.y = Y; sa.score = sscore_; sa.noise = noise; sa.seed = seed;
+    sa.x = sx_; sa.x_mean = sxm_; sa.y = Y; sa.score = sscore_; sa.noise = noise; sa.seed = set_seed(seed);
     sa.table = step_table_; sa.step_ptr = step_ctr_; sa.theta = sc.theta; sa.std1 = sc.std1; sa.n = (int)n;
     sa.score_w = sc.probability_flow ? 0.5f : 1.0f;
     sa.snr = sc.snr; sa.B = B; sa.per = F * T; sa.partial = lang_partial_; sa.lang = lang_scal_;
@@ -440,10 +440,12 @@ class Engine {
         SamplerArgs a = sa; a.draw_base = 1 + ncorr; a.draw_per_step = draws_per_step; a.add_noise = pred_noise ? 1 : 0;
         DRT_LAUNCH(sampler_revdiff_kernel, eg, dim3(256), stream_, a);
       }
+      // NonePredictor.update_fn returns (x, x) (predictors.py:69-76): xt_mean := xt also after a corrector moved them apart
+      if (sc.predictor == 0 && ncorr > 0) SG_CHECK(drt::memcpy_d2d(sxm_, sx_, n * 8, stream_));
       DRT_LAUNCH(step_inc_kernel, dim3(1), dim3(64), stream_, step_ctr_);
     };
 
-    GraphKey key{B, F, T, sc.corrector, ncorr, sc.predictor, sc.probability_flow + (affine ? 2 : 0), (const void*)Y, (const void*)noise, seed,
+    GraphKey key{B, F, T, sc.corrector, ncorr, sc.predictor, sc.probability_flow + (affine ? 2 : 0), (const void*)Y, (const void*)noise,
                  sc.theta + 1000.f * sc.snr * (sc.corrector == 2), draws_per_step};
     const bool want_graph = sc.use_graph && drt::graphs_supported();
     if (want_graph) {
@@ -453,7 +455,7 @@ class Engine {
         SG_CHECK(drt::graph_begin_capture(stream_));
         step_body();
         SG_CHECK(drt::graph_end_capture(stream_, &graph_));
-        graph_valid_ = true; graph_key_ = key;
+        graph_valid_ = true; graph_key_ = key; ++graph_captures_;
       }
       for (int i = 0; i < sc.N; ++i) SG_CHECK(drt::graph_launch(&graph_, stream_));
     } else {
@@ -493,7 +495,7 @@ class Engine {
     DRT_LAUNCH(step_set_kernel, dim3(1), dim3(64), stream_, step_ctr_, 0);
 
     SamplerArgs sa{};
-    sa.x = sx_; sa.x_mean = sxm_; sa.y = sy_; sa.score = sscore_; sa.noise = noise; sa.seed = seed;
+    sa.x = sx_; sa.x_mean = sxm_; sa.y = sy_; sa.score = sscore_; sa.noise = noise; sa.seed = set_seed(seed);
     sa.table = step_table_; sa.step_ptr = step_ctr_; sa.n = (int)n; sa.add_noise = stochastic ? 1 : 0;
     sa.draw_base = 0; sa.draw_per_step = 1;
     const dim3 eg((unsigned)((n + 255) / 256));
@@ -506,7 +508,7 @@ class Engine {
       DRT_LAUNCH(sampler_sb_kernel, eg, dim3(256), stream_, sa);
       DRT_LAUNCH(step_inc_kernel, dim3(1), dim3(64), stream_, step_ctr_);
     };
-    GraphKey key{B, F, T, 100 + stochastic, 0, 0, affine ? 2 : 0, nullptr, (const void*)noise, seed, 0.f, 1};
+    GraphKey key{B, F, T, 100 + stochastic, 0, 0, affine ? 2 : 0, nullptr, (const void*)noise, 0.f, 1};
     if (use_graph && drt::graphs_supported()) {
       if (!graph_valid_ || !(key == graph_key_)) {
         invalidate_graph();
@@ -514,7 +516,7 @@ class Engine {
         SG_CHECK(drt::graph_begin_capture(stream_));
         step_body();
         SG_CHECK(drt::graph_end_capture(stream_, &graph_));
-        graph_valid_ = true; graph_key_ = key;
+        graph_valid_ = true; graph_key_ = key; ++graph_captures_;
       }
       for (int i = 0; i < N; ++i) SG_CHECK(drt::graph_launch(&graph_, stream_));
     } else {
@@ -524,6 +526,7 @@ class Engine {
     nfe_ = N;
   }
   int last_nfe() const { return nfe_; }
+  int graph_captures() const { return graph_captures_; }     // how many times a step was captured + instantiated (tests, bench)
   int split_mode() const { return split_mode_; }
   size_t arena_bytes() const { return arena_cap_; }
 
@@ -659,10 +662,14 @@ class Engine {
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
     SG_REQUIRE(pl.mfma, "bench_conv: shape is not MFMA-eligible");
     if (variant >= 0 && (variant & 512)) { pl.rows = 4; variant &= ~512; }   // measurement knob: 128 co x 128 px tile
-    int ablate = 0, abl_split = 0;
+    int ablate = 0, abl_split = 0, stag = -1, stag_mode = 0;
+    bool split_rows4 = false;
     if (variant >= 0) {
-      abl_split = (variant >> 16) & 63;          // measurement knob: compile-time ablation of the split 3x3 kernel, bits 16..21
-      ablate = (variant >> 12) & 15;             // measurement knob: run-time ablation of the fp32 kernels, bits 12..15
+      stag = (variant >> 24) & 127;              // measurement knob: start-up stagger of the split 3x3 kernel, units per phase step
+      stag_mode = (variant >> 22) & 1;
+      split_rows4 = (variant >> 23) & 1;         // measurement knob: 4-row workgroup shape of the split 3x3 kernel
+      abl_split = (variant >> 12) & 1023;        // measurement knob: compile-time variant of the split 3x3 kernel, bits 12..21
+      if (!(variant & (64 | 128))) { ablate = abl_split & 15; abl_split = 0; }   // fp32 kernels: run-time ablation bits 12..15
       variant &= 4095;
     }
     const int smode = variant < 0 ? 0 : ((variant & 128) ? 2 : ((variant & 64) ? 1 : 0));
@@ -699,7 +706,15 @@ class Engine {
         a.amax1 = bounds;
       }
     }
-    auto go = [&]() { if (b3) launch_conv_split(a, ks, smode, stream_, false, abl_split); else launch_conv_mfma(a, ks, pl, stream_, variant); };
+    a.stagger_units = stag > 0 ? stag : 0; a.stagger_mode = stag_mode; a.stagger_slots = split_rows4 ? 768 : 512;
+    unsigned long long* trace_dev = nullptr;
+    const size_t n_wg = (size_t)B * ((H + 7) / 8) * ((W + 31) / 32) * ((Cout + 127) / 128);
+    if (abl_split & 64) {
+      trace_dev = static_cast<unsigned long long*>(dev_alloc_tmp(n_wg * 128));
+      SG_CHECK(drt::memset_dev(trace_dev, 0, n_wg * 128, stream_));
+      a.trace = trace_dev;
+    }
+    auto go = [&]() { if (b3) launch_conv_split(a, ks, smode, stream_, split_rows4, abl_split); else launch_conv_mfma(a, ks, pl, stream_, variant); };
     for (int i = 0; i < 2; ++i) go();
     drt::event_record(&e0, stream_);
     for (int i = 0; i < iters; ++i) go();
@@ -708,6 +723,13 @@ class Engine {
     const float ms = drt::event_elapsed_ms(e0, e1) / (float)iters;
     check_launch();
     drt::event_destroy(&e0); drt::event_destroy(&e1);
+    if (trace_dev) {                    // phase time stamps of the LAST launch -> $SGMSE_TRACE_OUT (binary: 16 x u64 per workgroup)
+      std::vector<unsigned long long> h(n_wg * 16);
+      SG_CHECK(drt::memcpy_d2h(h.data(), trace_dev, n_wg * 128, stream_));
+      SG_CHECK(drt::stream_sync(stream_));
+      if (const char* path = getenv("SGMSE_TRACE_OUT")) { if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); } }
+      free_tmp(trace_dev);
+    }
     for (float* q : {x, o, r, w, pk, sc}) free_tmp(q);
     if (pk3) free_tmp(const_cast<float*>(pk3));
     if (bounds) free_tmp(bounds);
@@ -1077,7 +1099,15 @@ class Engine {
       if (w.ks == 1 && w.split_mode == 2) { ca.amax1 = a.amax; ca.amax2 = b ? b->amax : nullptr; }
       // 4-row workgroups when 8-row ones would leave CUs idle (bit-identical results, so this may follow the batch size)
       const long nblk8 = (long)B_ * ((a.H + 7) / 8) * ((a.W + 31) / 32) * ((w.cout + 127) / 128);
-      launch_conv_split(ca, w.ks, w.split_mode, stream_, /*rows4=*/nblk8 < tile_min_blocks_);
+      const bool rows4 = nblk8 < tile_min_blocks_;
+      // start-up stagger (ConvArgs::stagger_units): only for launches of several residency rounds, where the one-time fill
+      // is small against what the de-phased rounds gain
+      const long slots = rows4 ? 768 : 512;
+      if (w.ks == 3 && split_stagger_ > 0 && (rows4 ? 2 * nblk8 : nblk8) >= 4 * slots) {
+        ca.stagger_units = (int)std::max(1L, (long)(Cin / 16) * split_stagger_ / 16 / 8128);
+        ca.stagger_slots = (int)slots; ca.stagger_mode = split_stagger_mode_;
+      }
+      launch_conv_split(ca, w.ks, w.split_mode, stream_, rows4);
       if (prof_ && prof_dump_)
         snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "");
       tick(w.ks == 3 ? (w.cout >= 128 ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
@@ -1309,13 +1339,24 @@ class Engine {
     drop(h4);
   }
 
+  // what a captured step depends on.  The Philox seed is NOT part of it: the sampler kernels read it from a device word
+  // (set_seed), so one capture serves every utterance / batch of a run (the Python samplers draw a fresh seed per call)
   struct GraphKey {
-    int B, F, T, corr, ncorr, pred, pf; const void* y; const void* noise; unsigned long long seed; float theta; int dps;
+    int B, F, T, corr, ncorr, pred, pf; const void* y; const void* noise; float theta; int dps;
     bool operator==(const GraphKey& o) const {
       return B == o.B && F == o.F && T == o.T && corr == o.corr && ncorr == o.ncorr && pred == o.pred && pf == o.pf && y == o.y &&
-             noise == o.noise && seed == o.seed && theta == o.theta && dps == o.dps;
+             noise == o.noise && theta == o.theta && dps == o.dps;
     }
   };
+  const unsigned long long* set_seed(unsigned long long seed) {
+    if (!seed_dev_) seed_dev_ = static_cast<unsigned long long*>(dev_alloc(256));
+    seed_host_ = seed;
+    SG_CHECK(drt::memcpy_h2d(seed_dev_, &seed_host_, 8, stream_));
+    SG_CHECK(drt::stream_sync(stream_));
+    return seed_dev_;
+  }
+  unsigned long long* seed_dev_ = nullptr; unsigned long long seed_host_ = 0;
+  int graph_captures_ = 0;
 
   int device_;
   drt::stream_t stream_;
@@ -1347,6 +1388,10 @@ class Engine {
     e = getenv("SGMSE_SPLIT_MIN_TILES");
     split_min_tiles_ = e ? atol(e) : 8L;                    // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
+    e = getenv("SGMSE_SPLIT_STAGGER");                   // start-up stagger of the split 3x3 kernel: cycles per K-stage of a tile (0: off)
+    split_stagger_ = e ? atol(e) : SGMSE_SPLIT_STAGGER_DEFAULT;
+    e = getenv("SGMSE_SPLIT_STAGGER_MODE");
+    split_stagger_mode_ = e ? atoi(e) : 0;
   }
   // per-forward range-bound slots ([B][kAmaxSpread] floats each), handed out in program order; counted by the dry run
   float* amax_pool_ = nullptr; size_t amax_pool_floats_ = 0; int amax_slots_ = 0, amax_next_ = 0;
@@ -1356,7 +1401,8 @@ class Engine {
     SG_REQUIRE(amax_pool_ && i < amax_slots_, "range-bound pool smaller than the forward needs");
     return amax_pool_ + (size_t)i * B_ * kAmaxSpread;
   }
-  long tile_min_blocks_ = 512, split_min_tiles_ = 8;
+  long tile_min_blocks_ = 512, split_min_tiles_ = 8, split_stagger_ = SGMSE_SPLIT_STAGGER_DEFAULT;
+  int split_stagger_mode_ = 0;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};

@@ -292,7 +292,7 @@ __device__ __forceinline__ float2 philox_cnormal(unsigned long long seed, unsign
 struct SamplerArgs {
   float2* x; float2* x_mean; const float2* y; const float2* score;
   const float2* noise;       // replayed noise [ndraws][B*FT] or null (Philox)
-  unsigned long long seed;
+  const unsigned long long* seed;   // device word: the Philox seed is data, not a kernel argument, so a captured step serves every seed
   const float* table; const int* step_ptr;
   int draw_base, draw_per_step;  // draw index = draw_base + step*draw_per_step
   float theta, score_w;     // score_w: 1 (reverse SDE) or 0.5 (probability flow)
@@ -307,7 +307,7 @@ struct SamplerArgs {
 
 __device__ __forceinline__ float2 sampler_noise(const SamplerArgs& p, int i, int draw) {
   if (p.noise) return p.noise[(size_t)draw * p.n + i];
-  return philox_cnormal(p.seed, (unsigned long long)i, (uint32_t)draw);
+  return philox_cnormal(*p.seed, (unsigned long long)i, (uint32_t)draw);
 }
 
 __global__ __launch_bounds__(256) void sampler_prior_kernel(SamplerArgs p) {

@@ -61,6 +61,14 @@ struct ConvArgs {
   // measurement-only ablation switches of the fp32 kernels for sgmse_bench_conv (results are then WRONG on purpose):
   // bit 2 stage only the first K-stage, bit 3 skip the barriers (the epilogue's switches are compile-time: conv_epilogue<ABL>)
   int ablate;
+  // Start-up stagger of the split 3x3 kernel (0: off).  Workgroups of the first residency round (linear id < stagger_slots)
+  // sleep phase * stagger_units * 8128 cycles, phase in 0..15, before they start: every workgroup of a launch takes the same
+  // time, so without it all resident workgroups stream their K-loops and then their epilogues in lockstep -- the matrix pipe
+  // idles while the whole chip reads residuals and writes outputs, and HBM idles during the K-loops
+  // (profiles/r02_split_ablation_microbench.txt: the phases add up instead of overlapping).
+  int stagger_units, stagger_slots, stagger_mode;
+  // measurement (ABL bit 6 instantiation): per workgroup {hw_id | xcc_id << 32, t_start, t_loop, t_epilogue, t_end} (shader clock)
+  unsigned long long* trace;
 };
 
 constexpr int kAmaxSpread = 64;
@@ -147,7 +155,8 @@ template <class T, int FC, int FP, int WC, bool GUARD, int ABL, bool PRE, bool R
 __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&acc)[FC][FP], int b, int co_blk, int tx, int ty,
                                                     int tiles_x, int wc, int wp, int l31, int kh, float as) {
   constexpr int CO_T = T::CO_T, ROWS = T::ROWS;
-  constexpr int PF = FP < 4 ? FP : 4;           // residual rows in flight (16 registers each)
+  constexpr int PF = (ABL & 128) ? 1 : (FP < 4 ? FP : 4);   // residual rows in flight (16 registers each)
+  constexpr int AUX = (ABL & 256) ? 2 : 0;
   const int H = p.H, W = p.W;
   const unsigned HW = (unsigned)H * (unsigned)W;
   const int x = tx * 32 + l31;
@@ -199,7 +208,7 @@ __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&
       for (int r = 0; r < 16; ++r) {
         const bool ok = rok && (!GUARD || co_l + (r & 3) + 8 * (r >> 2) < p.Cout);
         float t = 0.f;
-        if (ok) t = drt_buf_load(rbuf, lane_boff + (unsigned)j * (unsigned)W * 4u, soff(r));
+        if (ok) t = drt_buf_load<AUX>(rbuf, lane_boff + (unsigned)j * (unsigned)W * 4u, soff(r));
         rr[slot][r] = t;
       }
     };
@@ -221,7 +230,7 @@ __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&
         v *= p.out_scale;
         const bool ok = rok && (!GUARD || co_l + (r & 3) + 8 * (r >> 2) < p.Cout);
         if (ok && (!(ABL & 1) || v == 12345.678f))      // ABL bit 0 (measurement only): keep the value live without storing it
-          drt_buf_store(obuf, v, lane_boff + (unsigned)j * (unsigned)W * 4u, soff(r));
+          drt_buf_store<AUX>(obuf, v, lane_boff + (unsigned)j * (unsigned)W * 4u, soff(r));
         if (GUARD) v = ok ? v : 0.f;
         vmax = fmaxf(vmax, fabsf(v));
         sv[r] = v;
@@ -262,8 +271,9 @@ __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&
   return vmax;
 }
 
-// ABL (measurement-only instantiations of sgmse_bench_conv; results are then WRONG on purpose): bit 0 skip the global
-// stores, bit 1 skip the residual read
+// ABL (measurement-only instantiations of sgmse_bench_conv; with bits 0 / 1 results are WRONG on purpose): bit 0 skip the
+// global stores, bit 1 skip the residual read, bit 7 residual rows loaded right before their use, bit 8 non-temporal
+// cache policy on the residual loads and output stores
 // PRE: the kernel initialised its accumulators with (bias + bias2) / as (conv_acc_init), the epilogue adds no bias
 template <class T, int FC, int FP, int WC, int ABL = 0, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[FC][FP], int b, int co_blk, int tx, int ty,

@@ -184,7 +184,9 @@ inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<
 //
 // ABL: measurement-only instantiations reachable from sgmse_bench_conv (profiles/r02_split_ablation.txt), results WRONG on
 // purpose: 1 no epilogue stores, 2 no residual read, 4 producer without the transcendental pair, 8 nothing staged after
-// the first K-stage (no raw loads, producer, LDS writes), 16 B fragments read from LDS once, 32 A fragments loaded once.
+// the first K-stage (no raw loads, producer, LDS writes), 16 B fragments read from LDS once, 32 A fragments loaded once;
+// correct results: 64 phase time stamps per workgroup (ConvArgs::trace), 128 / 256 epilogue variants (conv_epilogue), 512 LDS
+// padded to one workgroup per CU.
 template <class S, int SHAPE = 0, int ACT = 1, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   constexpr bool THIN = SHAPE == 1;
@@ -206,6 +208,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   __shared__ float s_co[512 * NCO];
 
   const int tid = threadIdx.x;
+  if constexpr (ABL & 512) {          // one workgroup per CU: 48 KB of extra LDS
+    __shared__ u32x4 s_pad[3072];
+    if (p.ablate == 12345) s_pad[tid] = u32x4{0u, 0u, 0u, 0u};
+  }
+  unsigned long long* trace = nullptr;
+  if constexpr (ABL & 64) {
+    if (tid == 0 && p.trace) {
+      trace = p.trace + 16 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+      trace[0] = (unsigned long long)drt_hw_id() | ((unsigned long long)drt_xcc_id() << 32);
+      trace[1] = drt_clock();
+    }
+  }
+  if (p.stagger_units > 0) {          // de-phase the first residency round (ConvArgs::stagger_units)
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lin < (unsigned)p.stagger_slots) {
+      const unsigned h = (lin * 2654435761u) >> 28;                                       // 0..15, scattered
+      const unsigned ph = p.stagger_mode == 0 ? h : ((lin / ((unsigned)p.stagger_slots / 2)) & 1u) * 8u + (h >> 1);
+      for (unsigned i = 0; i < ph * (unsigned)p.stagger_units; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   const int Cin = p.C1 + p.C2;
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
@@ -384,13 +406,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   for (int i = 0; i < C::NIT; ++i) store_item(i, 0, s_in0);
   __syncthreads();
 
-  u32x4 a0[NS], a1[NS];
-  load_a(0, 0, a0);
+  if constexpr (ABL & 64) { if (trace) trace[2] = drt_clock(); }
+  // A fragments: a ring of three register sets, loaded TWO taps (48 MFMAs of this wave, ~2 us of a shared matrix pipe) ahead.
+  // Every wave of the CU shares one vector-memory queue: a fragment load (an L2 hit) regularly lands behind another wave's
+  // HBM misses (raw inputs of the next stage, the co-resident workgroup's residual reads), and one tap of cover exposed that
+  // latency on every tap (profiles/r02_split_ablation_microbench.txt: staging, fragment loads and the epilogue's memory
+  // traffic each ADDED their time to the K loop).  9 taps % 3 == 0: the ring index of a tap is the same in every stage.
+  unsigned long long tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // ABL 64: time per tap position and at the stage barrier (wave 0)
+  u32x4 ar[3][NS];
+  load_a(0, 0, ar[0]);
+  load_a(0, 1, ar[1]);
   if constexpr (ABL & 16) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) { bq[0][s] = s_in0[b_lane + s]; bq[1][s] = s_in0[b_lane + C::TCOLS * PX_V + s]; }
   }
-  if constexpr (ABL & 32) load_a(0, 1, a1);
+  if constexpr (ABL & 32) load_a(0, 2, ar[2]);
 #pragma unroll 1
   for (int st = 0; st < nst; ++st) {
     // the stage after this one, clamped: the last stage re-stages itself into the buffer nobody reads again, which
@@ -398,30 +428,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     const int stn = st + 1 < nst ? st + 1 : st;
     const u32x4* cur = (st & 1) ? s_in1 : s_in0;
     u32x4* nxt = (st & 1) ? s_in0 : s_in1;
-    // Per tap: the A fragments of the next tap first (vmcnt retires in order: they must be OLDER than the raw HBM loads
-    // of the next stage issued behind them, or every tap would wait for HBM), then one item of raw loads (taps 0-2);
+    // Per tap: the A fragments of the tap after next first (vmcnt retires in order: they must be OLDER than the raw HBM
+    // loads of the next stage issued behind them, or every tap would wait for HBM), then one item of raw loads (taps 0-2);
     // producer + split + LDS write of those items three or more taps later (taps 4, 6, 8).
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int ntap = tap + 1 < 9 ? tap + 1 : 0;
-      const int nstg = tap + 1 < 9 ? st : stn;
-      if constexpr (!(ABL & 32)) { if (tap & 1) load_a(nstg, ntap, a0); else load_a(nstg, ntap, a1); }
+      unsigned long long tc0 = 0;
+      if constexpr (ABL & 64) tc0 = drt_clock();
+      const int ntap = (tap + 2) % 9;
+      const int nstg = tap + 2 < 9 ? st : stn;
+      if constexpr (!(ABL & 32)) load_a(nstg, ntap, ar[(tap + 2) % 3]);
       if constexpr (!(ABL & 8)) { if (tap < C::NIT) load_item(tap, stn * C::KC); }
       __builtin_amdgcn_sched_barrier(0);
       int item = (tap >= 4 && (tap & 1) == 0 && (tap - 4) / 2 < C::NIT) ? (tap - 4) / 2 : -1;   // taps 4, 6, 8: items 0, 1, 2
       if constexpr (ABL & 8) item = -1;
-      if (tap & 1) compute_tap(cur, tap, a1, item, stn * C::KC, nxt); else compute_tap(cur, tap, a0, item, stn * C::KC, nxt);
+      compute_tap(cur, tap, ar[tap % 3], item, stn * C::KC, nxt);
+      if constexpr (ABL & 64) { __builtin_amdgcn_sched_barrier(0); tsum[tap] += drt_clock() - tc0; }
     }
-    __syncthreads();
-    // nine taps: the register sets have swapped roles (tap 8 computed from a0 and prefetched the next stage into a1)
-    if constexpr (!(ABL & 32)) {
+    if constexpr (ABL & 64) {
+      const unsigned long long tb = drt_clock();
+      __syncthreads();
+      tsum[9] += drt_clock() - tb;
+    } else {
+      __syncthreads();
+    }
+  }
+  if constexpr (ABL & 64) {
+    if (trace) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) a0[s] = a1[s];
+      for (int i = 0; i < 10; ++i) trace[5 + i] = tsum[i];
     }
   }
 
+  if constexpr (ABL & 64) { if (trace) trace[3] = drt_clock(); }
   if constexpr (THIN) conv_epilogue<T, 1, FPW, 1, ABL & 3, true>(p, acc, b, co_blk, tx, ty, tiles_x, 0, wave, l31, kg);
-  else conv_epilogue<T, 1, FPW, 4, ABL & 3, true>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);
+  else conv_epilogue<T, 1, FPW, 4, ABL & (3 | 128 | 256), true>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);
+  if constexpr (ABL & 64) { if (trace) trace[4] = drt_clock(); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -43,12 +43,19 @@ struct drt_buf { __amdgpu_buffer_rsrc_t r; };
 __device__ __forceinline__ drt_buf drt_make_buf(const float* base) {
   return drt_buf{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000)};
 }
+// AUX: cache-policy bits of the instruction (0 default, 2 = nt: streaming data that is not read again soon)
+template <int AUX = 0>
 __device__ __forceinline__ float drt_buf_load(const drt_buf& b, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void drt_buf_store(const drt_buf& b, float v, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, voff, soff, AUX);
 }
+// measurement: shader clock and the hardware placement of this wave (HW_REG_HW_ID, HW_REG_XCC_ID)
+__device__ __forceinline__ unsigned long long drt_clock() { return __builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ unsigned drt_hw_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 4); }
+__device__ __forceinline__ unsigned drt_xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20); }
 // atomic max of non-negative floats (their bit patterns order like unsigned integers)
 __device__ __forceinline__ void drt_atomic_max_nonneg(float* p, float v) {
   atomicMax(reinterpret_cast<unsigned int*>(p), __builtin_bit_cast(unsigned int, v));

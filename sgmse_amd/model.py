@@ -8,6 +8,10 @@ swaps the EMA weights in on ``eval()`` as the reference does (model.py:111-125),
 """
 from __future__ import annotations
 
+import contextlib
+import importlib
+import os
+import sys
 import time
 import warnings
 from math import ceil
@@ -21,6 +25,25 @@ from .backbones import BackboneRegistry
 from .data_module import SpecsDataModule
 from .sdes import SDERegistry
 from .util.other import pad_spec
+
+
+@contextlib.contextmanager
+def _reference_package_alias():
+    """Make ``import sgmse[.x.y]`` resolve to sgmse_amd (the alias package sgmse_amd/compat/sgmse) while a checkpoint written by
+    the reference is unpickled.  A real ``sgmse`` package that is already imported is left alone."""
+    if "sgmse" in sys.modules:
+        yield
+        return
+    compat = os.path.join(os.path.dirname(os.path.abspath(__file__)), "compat")
+    sys.path.insert(0, compat)
+    try:
+        importlib.import_module("sgmse")
+        yield
+    finally:
+        try:
+            sys.path.remove(compat)
+        except ValueError:
+            pass
 
 
 class ScoreModel(nn.Module):
@@ -66,7 +89,10 @@ class ScoreModel(nn.Module):
         """Read a Lightning ``.ckpt`` written by the reference's train.py without
         pytorch_lightning: ``hyper_parameters`` -> constructor, ``state_dict`` (keys ``dnn.*``) -> backbone,
         ``ema`` -> shadow parameters used by ``eval()``."""
-        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        # the reference's train.py pickles classes of its own package (sgmse.data_module.SpecsDataModule in hyper_parameters):
+        # resolve that package name to this implementation for the duration of the unpickling
+        with _reference_package_alias():
+            ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
         hp = dict(ckpt.get("hyper_parameters", {}))
         hp.update(overrides)
         hp.pop("no_wandb", None)
@@ -264,37 +290,38 @@ class ScoreModel(nn.Module):
     def _device(self):
         return next(self.dnn.parameters()).device
 
+    def _sampler_for(self, Y, predictor, corrector, N, corrector_steps, snr, **kwargs):
+        """The zero-argument sampler ``enhance`` runs for a padded spectrogram Y, chosen by the model's SDE and the SDE's
+        ``sampler_type`` attribute as in reference model.py:440-452 (and enhancement.py:77-94)."""
+        kind = type(self.sde).__name__
+        if kind == "SBVESDE":
+            return self.get_sb_sampler(sde=self.sde, y=Y, sampler_type=self.sde.sampler_type, **kwargs)
+        if kind != "OUVESDE":
+            raise ValueError("Invalid SDE type for speech enhancement: {}".format(kind))
+        which = self.sde.sampler_type
+        if which == "pc":
+            return self.get_pc_sampler(predictor, corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr, intermediate=False,
+                                       **kwargs)
+        if which == "ode":
+            return self.get_ode_sampler(Y, N=N, **kwargs)
+        raise ValueError("Invalid sampler type for SGMSE sampling: {}".format(which))
+
     def enhance(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=30, corrector_steps=1, snr=0.5,
                 timeit=False, **kwargs):
-        """One-call enhancement of a noisy waveform y [1, L] (reference model.py:426-465): normalise, STFT, spec_fwd,
-        zero-pad, sample, spec_back, iSTFT, renormalise; returns a NumPy array (and nfe, RTF with ``timeit``)."""
-        start = time.time()
-        dev = self._device()
-        T_orig = y.size(1)
-        norm_factor = y.abs().max().item()
-        y = y / norm_factor
-        Y = torch.unsqueeze(self._forward_transform(self._stft(y.to(dev))), 0)
-        Y = pad_spec(Y)
-        if self.sde.__class__.__name__ == "OUVESDE":
-            if self.sde.sampler_type == "pc":
-                sampler = self.get_pc_sampler(predictor, corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr,
-                                              intermediate=False, **kwargs)
-            elif self.sde.sampler_type == "ode":
-                sampler = self.get_ode_sampler(Y, N=N, **kwargs)
-            else:
-                raise ValueError("Invalid sampler type for SGMSE sampling: {}".format(sampler_type))
-        elif self.sde.__class__.__name__ == "SBVESDE":
-            sampler = self.get_sb_sampler(sde=self.sde, y=Y, sampler_type=self.sde.sampler_type, **kwargs)
-        else:
-            raise ValueError("Invalid SDE type for speech enhancement: {}".format(self.sde.__class__.__name__))
+        """One-call enhancement of a noisy waveform y [1, L] (signature and result of reference model.py:426-465): peak
+        normalisation -> STFT -> spec_fwd -> zero-pad -> sampler -> spec_back -> iSTFT -> undo the normalisation.  Returns a
+        NumPy array; with ``timeit`` also nfe and the real-time factor.  (``sampler_type`` is accepted and, like in the
+        reference, overridden by the SDE's own ``sampler_type``.)"""
+        t_begin = time.time()
+        n_samples = y.size(1)
+        peak = y.abs().max().item()
+        spec = self._forward_transform(self._stft((y / peak).to(self._device())))
+        sampler = self._sampler_for(pad_spec(spec.unsqueeze(0)), predictor, corrector, N, corrector_steps, snr, **kwargs)
         sample, nfe = sampler()
-        x_hat = self.to_audio(sample.squeeze(), T_orig)
-        x_hat = x_hat * norm_factor
-        x_hat = x_hat.squeeze().cpu().numpy()
-        end = time.time()
-        if timeit:
-            return x_hat, nfe, (end - start) / (len(x_hat) / self.sr)
-        return x_hat
+        wave = (self.to_audio(sample.squeeze(), n_samples) * peak).squeeze().cpu().numpy()
+        if not timeit:
+            return wave
+        return wave, nfe, (time.time() - t_begin) / (len(wave) / self.sr)
 
     def enhance_batch(self, y, N=30, corrector="ald", corrector_steps=1, snr=0.5, pad_mode="zero_pad", noise=None, seed=None,
                       predictor="reverse_diffusion", sampler_type="pc", use_graph=True):

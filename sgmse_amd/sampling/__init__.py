@@ -9,6 +9,7 @@ classes, with every score evaluation still running on the HIP network.
 """
 from __future__ import annotations
 
+import warnings
 from typing import Optional
 
 import torch
@@ -95,6 +96,11 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
     implementation is the fixed-step counterpart on the sampler's own time grid: N Euler steps of
     ``sde.reverse(score_fn, probability_flow=True).discretize`` (sdes.py:130-135), x <- x - rev_f, no noise, N NFE,
     as one HIP loop.  ``rtol/atol/method/inverse_scaler/device`` are accepted and ignored."""
+    ignored = [k for k, v, d in (("rtol", rtol, 1e-5), ("atol", atol, 1e-5), ("method", method, "RK45"), ("denoise", denoise, True),
+                                 ("inverse_scaler", inverse_scaler, None)) if v != d]
+    if ignored:
+        warnings.warn(f"get_ode_sampler: {', '.join(ignored)} ignored -- this is the fixed-step probability-flow Euler sampler (N steps, "
+                      f"N NFE), not the reference's adaptive scipy solver; results are not comparable with a reference ODE run")
     ctx = _native_engine(score_fn, y) if isinstance(sde, OUVESDE) else None
     if ctx is None:
         rsde = sde.reverse(score_fn, probability_flow=True)

@@ -23,7 +23,9 @@ def _bshape(v: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
 
 
 class SDE(abc.ABC):
-    """Abstract SDE; N = number of discretisation steps (reference sdes.py:19-30)."""
+    """A forward SDE dx = f(x, y, t) dt + g(t) dw on t in [0, T], discretised in N steps (reference sdes.py:19-30).
+    Subclasses provide the coefficients (``sde``), the perturbation kernel (``marginal_prob``), the prior and ``copy``;
+    the base supplies the Euler-Maruyama discretisation and the time reversal."""
 
     def __init__(self, N):
         super().__init__()
@@ -32,92 +34,105 @@ class SDE(abc.ABC):
     @property
     @abc.abstractmethod
     def T(self):
-        ...
+        """End time."""
 
     @abc.abstractmethod
     def sde(self, x, y, t, *args):
-        ...
+        """(drift [B,...], diffusion [B])."""
 
     @abc.abstractmethod
     def marginal_prob(self, x, y, t, *args):
-        ...
+        """(mean, std) of p_t(x | x0, y)."""
 
     @abc.abstractmethod
     def prior_sampling(self, shape, *args):
-        ...
+        """A sample of p_T."""
 
     @staticmethod
     @abc.abstractmethod
     def add_argparse_args(parent_parser):
-        ...
+        """Register the SDE's command-line flags."""
 
     @abc.abstractmethod
     def copy(self):
-        ...
+        """An independent instance with the same parameters."""
 
     def discretize(self, x, y, t, stepsize):
-        """Euler-Maruyama discretisation f = drift*dt, G = diffusion*sqrt(dt) (reference sdes.py:72-89)."""
-        dt = stepsize
+        """One Euler-Maruyama step of size ``stepsize``: (f, G) = (drift * dt, diffusion * sqrt(dt)), so that
+        x_{i+1} = x_i + f + G z (reference sdes.py:72-89)."""
         drift, diffusion = self.sde(x, y, t)
-        return drift * dt, diffusion * torch.sqrt(dt)
+        return drift * stepsize, diffusion * torch.sqrt(stepsize)
 
-    def reverse(oself, score_model, probability_flow=False):
-        """The reverse-time SDE / probability-flow ODE as an object with ``sde``, ``rsde_parts`` and ``discretize``
-        (reference sdes.py:91-137)."""
-        N, T = oself.N, oself.T
-        fwd_sde, fwd_disc = oself.sde, oself.discretize
+    def reverse(self, score_model, probability_flow=False):
+        """Time reversal driven by ``score_model(x, y, t)`` (reference sdes.py:91-137): the reverse SDE, or with
+        ``probability_flow`` the deterministic ODE with the same marginals."""
+        return ReverseSDE(self, score_model, probability_flow)
 
-        class RSDE(oself.__class__):
-            def __init__(self):
-                self.N = N
-                self.probability_flow = probability_flow
 
-            @property
-            def T(self):
-                return T
+class ReverseSDE:
+    """Reverse-time counterpart of a forward SDE (Anderson 1982; Song et al. 2021):
 
-            def rsde_parts(self, x, y, t, *args):
-                sde_drift, sde_diffusion = fwd_sde(x, y, t, *args)
-                score = score_model(x, y, t, *args)
-                score_drift = -_bshape(sde_diffusion, x) ** 2 * score * (0.5 if self.probability_flow else 1.0)
-                diffusion = torch.zeros_like(sde_diffusion) if self.probability_flow else sde_diffusion
-                return {"total_drift": sde_drift + score_drift, "diffusion": diffusion, "sde_drift": sde_drift,
-                        "sde_diffusion": sde_diffusion, "score_drift": score_drift, "score": score}
+        dx = [f(x, y, t) - w g(t)^2 score(x, y, t)] dt + g~(t) dw~,      (w, g~) = (1, g)  or, probability flow, (1/2, 0)
 
-            def sde(self, x, y, t, *args):
-                parts = self.rsde_parts(x, y, t, *args)
-                return parts["total_drift"], parts["diffusion"]
+    The reference builds this object as a class nested in ``SDE.reverse`` and derived from the forward SDE's own class
+    (sdes.py:98-137); here it is a plain wrapper with the same public methods (``N``, ``T``, ``sde``, ``rsde_parts``,
+    ``discretize``) and the same arithmetic per method."""
 
-            def discretize(self, x, y, t, stepsize):
-                f, G = fwd_disc(x, y, t, stepsize)
-                rev_f = f - _bshape(G, x) ** 2 * score_model(x, y, t) * (0.5 if self.probability_flow else 1.0)
-                rev_G = torch.zeros_like(G) if self.probability_flow else G
-                return rev_f, rev_G
+    def __init__(self, forward, score_model, probability_flow=False):
+        self.forward, self.score_model = forward, score_model
+        self.probability_flow = probability_flow
+        self.N = forward.N
 
-        return RSDE()
+    @property
+    def T(self):
+        return self.forward.T
+
+    @property
+    def _score_weight(self):
+        return 0.5 if self.probability_flow else 1.0
+
+    def rsde_parts(self, x, y, t, *args):
+        """Every term of the reverse drift by name (used by diagnostics in the reference)."""
+        f, g = self.forward.sde(x, y, t, *args)
+        score = self.score_model(x, y, t, *args)
+        from_score = -_bshape(g, x) ** 2 * score * self._score_weight
+        return {"total_drift": f + from_score, "diffusion": torch.zeros_like(g) if self.probability_flow else g,
+                "sde_drift": f, "sde_diffusion": g, "score_drift": from_score, "score": score}
+
+    def sde(self, x, y, t, *args):
+        parts = self.rsde_parts(x, y, t, *args)
+        return parts["total_drift"], parts["diffusion"]
+
+    def discretize(self, x, y, t, stepsize):
+        """(rev_f, rev_G) of one step: x_{i-1} = x_i - rev_f + rev_G z."""
+        f, G = self.forward.discretize(x, y, t, stepsize)
+        rev_f = f - _bshape(G, x) ** 2 * self.score_model(x, y, t) * self._score_weight
+        return rev_f, (torch.zeros_like(G) if self.probability_flow else G)
 
 
 @SDERegistry.register("ouve")
 class OUVESDE(SDE):
-    """Ornstein-Uhlenbeck variance-exploding SDE  dx = theta (y - x) dt + sigma(t) dw,
-    sigma(t) = sigma_min (sigma_max/sigma_min)^t sqrt(2 log(sigma_max/sigma_min))  (reference sdes.py:144-232)."""
+    """Ornstein-Uhlenbeck drift towards the noisy spectrogram y with a variance-exploding diffusion (reference
+    sdes.py:144-232; Richter et al. 2023):
+
+        dx = theta (y - x) dt + g(t) dw,     g(t) = sigma_min (sigma_max / sigma_min)^t sqrt(2 lambda),   lambda = ln(sigma_max / sigma_min)
+
+    so that x_t | x_0, y is Gaussian with mean e^{-theta t} x_0 + (1 - e^{-theta t}) y and variance
+    sigma_min^2 e^{-2 theta t} (e^{2 (theta + lambda) t} - 1) lambda / (theta + lambda)."""
 
     @staticmethod
     def add_argparse_args(parser):
-        parser.add_argument("--theta", type=float, default=1.5, help="Stiffness of the Ornstein-Uhlenbeck process (1.5).")
-        parser.add_argument("--sigma-min", type=float, default=0.05, help="Smallest sigma (0.05).")
-        parser.add_argument("--sigma-max", type=float, default=0.5, help="Largest sigma (0.5).")
-        parser.add_argument("--N", type=int, default=30, help="Number of discretisation steps (30).")
-        parser.add_argument("--sampler_type", type=str, default="pc", help="Sampler used by ScoreModel.enhance ('pc').")
+        parser.add_argument("--theta", type=float, default=1.5, help="Stiffness of the OU drift (default 1.5).")
+        parser.add_argument("--sigma-min", type=float, default=0.05, help="Diffusion scale at t = 0 (default 0.05).")
+        parser.add_argument("--sigma-max", type=float, default=0.5, help="Diffusion scale at t = 1 (default 0.5).")
+        parser.add_argument("--N", type=int, default=30, help="Discretisation steps of the reverse process (default 30).")
+        parser.add_argument("--sampler_type", type=str, default="pc", help="Sampler ScoreModel.enhance uses ('pc' or 'ode').")
         return parser
 
     def __init__(self, theta, sigma_min, sigma_max, N=30, sampler_type="pc", **ignored_kwargs):
         super().__init__(N)
-        self.theta = theta
-        self.sigma_min = sigma_min
-        self.sigma_max = sigma_max
-        self.logsig = np.log(self.sigma_max / self.sigma_min)
-        self.N = N
+        self.theta, self.sigma_min, self.sigma_max = theta, sigma_min, sigma_max
+        self.logsig = np.log(self.sigma_max / self.sigma_min)         # lambda (a NumPy float64, as in the reference)
         self.sampler_type = sampler_type
 
     def copy(self):
@@ -127,29 +142,30 @@ class OUVESDE(SDE):
     def T(self):
         return 1
 
+    def _g(self, t):
+        return self.sigma_min * (self.sigma_max / self.sigma_min) ** t * np.sqrt(2 * self.logsig)
+
     def sde(self, x, y, t):
-        drift = self.theta * (y - x)
-        sigma = self.sigma_min * (self.sigma_max / self.sigma_min) ** t
-        diffusion = sigma * np.sqrt(2 * self.logsig)
-        return drift, diffusion
+        return self.theta * (y - x), self._g(t)
 
     def _mean(self, x0, y, t):
-        w = _bshape(torch.exp(-self.theta * t), x0)
-        return w * x0 + (1 - w) * y
+        decay = _bshape(torch.exp(-self.theta * t), x0)
+        return decay * x0 + (1 - decay) * y
 
     def _std(self, t):
-        smin, theta, logsig = self.sigma_min, self.theta, self.logsig
-        return torch.sqrt((smin ** 2 * torch.exp(-2 * theta * t) * (torch.exp(2 * (theta + logsig) * t) - 1) * logsig)
-                          / (theta + logsig))
+        lam, th = self.logsig, self.theta
+        var = (self.sigma_min ** 2 * torch.exp(-2 * th * t) * (torch.exp(2 * (th + lam) * t) - 1) * lam) / (th + lam)
+        return torch.sqrt(var)
 
     def marginal_prob(self, x0, y, t):
         return self._mean(x0, y, t), self._std(t)
 
     def prior_sampling(self, shape, y):
+        """x_T = y + std(T) z (the mean term e^{-theta T} x_0 is dropped: x_0 is unknown at inference time)."""
         if shape != y.shape:
             warnings.warn(f"Target shape {shape} does not match shape of y {y.shape}! Ignoring target shape.")
-        std = self._std(torch.ones((y.shape[0],), device=y.device))
-        return y + torch.randn_like(y) * _bshape(std, y)
+        std_T = self._std(torch.ones((y.shape[0],), device=y.device))
+        return y + torch.randn_like(y) * _bshape(std_T, y)
 
     def prior_logp(self, z):
         raise NotImplementedError("prior_logp for OU SDE not yet implemented!")

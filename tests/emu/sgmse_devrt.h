@@ -64,8 +64,13 @@ static inline uint32_t drt_f32_to_f16(float x) { return emu::f32_to_f16(x); }
 static inline float drt_f16_to_f32(uint32_t h) { return emu::f16_to_f32(h); }
 struct drt_buf { char* p; };
 static inline drt_buf drt_make_buf(const float* base) { return drt_buf{reinterpret_cast<char*>(const_cast<float*>(base))}; }
+template <int AUX = 0>
 static inline float drt_buf_load(const drt_buf& b, unsigned voff, unsigned soff) { float v; memcpy(&v, b.p + voff + soff, 4); return v; }
+template <int AUX = 0>
 static inline void drt_buf_store(const drt_buf& b, float v, unsigned voff, unsigned soff) { memcpy(b.p + voff + soff, &v, 4); }
+static inline unsigned long long drt_clock() { return 0; }
+static inline unsigned drt_hw_id() { return 0; }
+static inline unsigned drt_xcc_id() { return 0; }
 static inline uint32_t drt_f32x2_to_f16x2(float x0, float x1) { return emu::f32_to_f16(x0) | (emu::f32_to_f16(x1) << 16); }
 static inline float drt_exp2(float x) { return exp2f(x); }
 static inline void drt_atomic_max_nonneg(float* p, float v) {

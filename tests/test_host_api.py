@@ -314,3 +314,130 @@ def test_calc_metrics_on_a_wav_directory(tmp_path):
         np.testing.assert_allclose((data["si_sdr"][i], data["si_sir"][i], data["si_sar"][i]), expect[fn], rtol=1e-9)
     assert (dirs["enh"] / "_results.csv").read_text().splitlines()[0] == "filename,pesq,estoi,si_sdr,si_sir,si_sar"
     assert "SI-SDR:" in (dirs["enh"] / "_avg_results.txt").read_text()
+
+
+def test_checkpoint_that_pickles_the_reference_package_name(tmp_path):
+    """A checkpoint written by the reference's train.py pickles ``sgmse.data_module.SpecsDataModule`` (a GLOBAL opcode naming
+    the reference package) inside hyper_parameters.  load_from_checkpoint must resolve it without sgmse_amd/compat being on
+    PYTHONPATH (child process: no alias set up by the caller)."""
+    import pickle
+    from sgmse_amd.model import ScoreModel
+    hp = dict(backbone="ncsnpp", sde="ouve", nf=32, theta=1.5, sigma_min=0.05, sigma_max=0.5, N=30, t_eps=0.03)
+    src = ScoreModel(**hp)
+    path = tmp_path / "ref.ckpt"
+    torch.save({"state_dict": {"dnn." + k: v.clone() for k, v in src.dnn.state_dict().items()},
+                "hyper_parameters": dict(hp, data_module_cls="PLACEHOLDER")}, path)
+    # rewrite the placeholder into the pickle opcode sequence `GLOBAL sgmse.data_module SpecsDataModule`
+    import zipfile
+    with zipfile.ZipFile(path) as z:
+        names = z.namelist()
+        blobs = {n: z.read(n) for n in names}
+    pkl = [n for n in names if n.endswith("data.pkl")][0]
+    marker = pickle.dumps("PLACEHOLDER", protocol=2)[2:-1]          # BINUNICODE + payload (+ memo put), without PROTO / STOP
+    assert blobs[pkl].count(marker[:16]) == 1
+    head = marker[:5 + len("PLACEHOLDER")]
+    blobs[pkl] = blobs[pkl].replace(head, b"csgmse.data_module\nSpecsDataModule\n", 1)
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
+        for n in names:
+            z.writestr(n, blobs[n])
+    code = ("import sys, warnings; sys.path.insert(0, %r)\n"
+            "warnings.simplefilter('ignore')\n"
+            "assert 'sgmse' not in sys.modules\n"
+            "from sgmse_amd.model import ScoreModel\n"
+            "from sgmse_amd.data_module import SpecsDataModule\n"
+            "m = ScoreModel.load_from_checkpoint(%r)\n"
+            "assert m.hparams['data_module_cls'] is SpecsDataModule and isinstance(m.data_module, SpecsDataModule)\n"
+            "assert not any(p.endswith('compat') for p in sys.path)\n"
+            "print('CKPT-OK', m.backbone)\n") % (ROOT, str(path))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
+    assert "CKPT-OK ncsnpp" in out.stdout, out.stdout + out.stderr
+
+
+def test_euler_maruyama_predictor_is_pinned_to_the_reference_behaviour():
+    """'euler_maruyama' cannot run inside the PC loop, in the reference as here: the loop hands ``stepsize`` to update_fn,
+    which forwards it into OUVESDE.sde(x, y, t) (predictors.py:49 -> sdes.py:114-120) -> TypeError.  Called directly it is
+    the Euler-Maruyama step of the reverse SDE (oracle: euler_maruyama_update)."""
+    from sgmse_amd import sampling
+    from sgmse_amd.sdes import OUVESDE
+    from oracle import sde_oracle as SO
+    y = torch.randn(2, 1, 8, 16, dtype=torch.complex64, generator=torch.Generator().manual_seed(0))
+    score = lambda x, yy, t: (yy - x) * 0.7
+    sde = OUVESDE(1.5, 0.05, 0.5, N=5)
+    with pytest.raises(TypeError):
+        sampling.get_pc_sampler("euler_maruyama", "none", sde, score, y, eps=0.03)()
+    pred = sampling.PredictorRegistry.get_by_name("euler_maruyama")(sde, score)
+    t = torch.full((2,), 0.6)
+    rep, rep2 = SO.NoiseReplay(3), SO.NoiseReplay(3)
+    ref, ref_mean = SO.euler_maruyama_update(SO.OUVE(1.5, 0.05, 0.5, 5), score, y, y * 0.5, t, rep)
+    orig = torch.randn_like
+    torch.randn_like = lambda like, **kw: rep2(like)
+    try:
+        out, mean = pred.update_fn(y, y * 0.5, t)
+    finally:
+        torch.randn_like = orig
+    assert rel_l2(out, ref) < 1e-6 and rel_l2(mean, ref_mean) < 1e-6
+
+
+def test_ode_sampler_warns_about_ignored_solver_arguments():
+    from sgmse_amd import sampling
+    from sgmse_amd.sdes import OUVESDE
+    y = torch.zeros(1, 1, 8, 16, dtype=torch.complex64)
+    score = lambda x, yy, t: yy - x
+    with pytest.warns(UserWarning, match="rtol"):
+        sampling.get_ode_sampler(OUVESDE(1.5, 0.05, 0.5, N=3), score, y, rtol=1e-3)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        out, nfe = sampling.get_ode_sampler(OUVESDE(1.5, 0.05, 0.5, N=3), score, y)()
+    assert nfe == 3 and out.shape == y.shape
+
+
+def test_minibatch_samplers_equal_one_big_batch(emu):
+    """get_pc_sampler / get_ode_sampler(minibatch=m) (reference model.py:356-368, 378-390) run the batch in serial chunks;
+    utterances are independent, so with replayed noise the chunks reproduce the big batch."""
+    import parity as P
+    from oracle import ncsnpp_oracle as NO, synth
+    cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
+    m, _ = P.make_model(cfg, emu)
+    y = synth.synth_spec(3, 256, 64, seed=3)
+    N = 1
+    full, nfe = m.get_pc_sampler("reverse_diffusion", "ald", y, N=N, snr=0.5, noise=P.replay_noise(y.shape, 1 + 2 * N))()
+    assert nfe == 2 * N
+    # same draws per utterance: chunk i of size 2 replays rows [2i, 2i+2) of every draw
+    outs = []
+    for lo in (0, 2):
+        yy = y[lo:lo + 2]
+        noise = P.replay_noise(y.shape, 1 + 2 * N)[:, lo:lo + 2].contiguous()
+        outs.append(m.get_pc_sampler("reverse_diffusion", "ald", yy, N=N, snr=0.5, noise=noise)()[0])
+    assert torch.equal(torch.cat(outs), full)
+    # the minibatch wrapper itself: seeded Philox noise depends on the slot inside a chunk, so compare its structure
+    got, ns = m.get_pc_sampler("reverse_diffusion", "ald", y, N=N, snr=0.5, minibatch=2, seed=5)()
+    assert got.shape == y.shape and ns == [2 * N, 2 * N]
+    a, _ = m.get_pc_sampler("reverse_diffusion", "ald", y[:2], N=N, snr=0.5, seed=5)()
+    b, _ = m.get_pc_sampler("reverse_diffusion", "ald", y[2:], N=N, snr=0.5, seed=5)()
+    assert torch.equal(got, torch.cat([a, b]))
+    got, ns = m.get_ode_sampler(y, N=2, minibatch=2, seed=5)()
+    assert got.shape == y.shape and ns == [2, 2]
+
+
+def test_none_predictor_behind_a_corrector_returns_the_noisy_iterate(emu):
+    """NonePredictor.update_fn returns (x, x) (predictors.py:69-76): with a corrector in front, xt_mean is overwritten by the
+    noisy xt, so denoise=True returns xt.  Fused loop == reference-style Python loop over the same network and noise."""
+    import parity as P
+    from oracle import ncsnpp_oracle as NO, sde_oracle as SO, synth
+    cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
+    m, Pm = P.make_model(cfg, emu)
+    y = synth.synth_spec(1, 256, 64, seed=3)
+    N = 2
+    rep = SO.NoiseReplay(7)
+    score = lambda a, b, c: NO.score_fn(Pm, cfg, a, b, c)
+    ref, nfe_ref = SO.pc_sample(SO.OUVE(1.5, 0.05, 0.5, N), score, y, rep, eps=0.03, snr=0.5, corrector="ald", predictor="none")
+    ref_noisy, _ = SO.pc_sample(SO.OUVE(1.5, 0.05, 0.5, N), score, y, SO.NoiseReplay(7), eps=0.03, snr=0.5, corrector="ald",
+                                predictor="none", denoise=False)
+    assert torch.equal(ref, ref_noisy)            # x_mean == x behind a NonePredictor
+    noise = torch.stack(rep.draws)
+    out, nfe = m.get_pc_sampler("none", "ald", y, N=N, snr=0.5, noise=noise)()
+    assert nfe == nfe_ref and rel_l2(out, ref) < 1e-4
+    out2, _ = m.get_pc_sampler("none", "ald", y, N=N, snr=0.5, noise=noise, use_graph=False)()
+    assert torch.equal(out, out2)

@@ -7,9 +7,9 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 STEPS=${STEPS:-tests,abl,pmc,bench}
 has() { [[ ",$STEPS," == *",$1,"* ]]; }
-# variant = 128 (fp16x2 split kernel) | ablation << 16: 0 full, 3 no epilogue stores/residual, 4 no exp/rcp, 8 nothing staged
+# variant = 128 (fp16x2 split kernel) | ablation << 12: 0 full, 3 no epilogue stores/residual, 4 no exp/rcp, 8 nothing staged
 # after stage 0, 24 + B fragments read once, 56 + A fragments loaded once (MFMA-only loop), 59 + no epilogue memory traffic
-ABL_VARIANTS="128,$((128 + (3<<16))),$((128 + (4<<16))),$((128 + (8<<16))),$((128 + (24<<16))),$((128 + (56<<16))),$((128 + (59<<16)))"
+ABL_VARIANTS="128,$((128 + (3<<12))),$((128 + (4<<12))),$((128 + (8<<12))),$((128 + (24<<12))),$((128 + (56<<12))),$((128 + (59<<12)))"
 if has tests; then
   echo "== targeted pytest -m gpu"
   timeout 1500 python -m pytest tests -m gpu -q -x -p no:cacheprovider -s -k "${TEST_K:-conv or groupnorm or forward or split or baseline_configuration or batch_of_four or tile_shape or sampler}" > gpurun_out/pytest_gpu_targeted.log 2>&1
