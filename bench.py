@@ -34,9 +34,9 @@ DOMINANT = {   # conv split mode -> (kernel, effective peak, how the peak is der
     0: ("conv_mfma_pipe_kernel<3,2,2,4> (3x3 fp32 MFMA implicit GEMM, 128 co x 256 px tile)", FP32_PEAK_TFLOPS,
         "fp32 MFMA peak", "void sgmse::conv_mfma_kernel<3, 2, 2, 4"),
     1: ("conv3x3_split_kernel<SplitB3> (3x3 implicit GEMM, exact 3-way bf16 operand split, 6 partial products, fp32 accumulate)",
-        MFMA16_PEAK_TFLOPS / 6, "dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per multiply", "void sgmse::conv3x3_split_kernel<sgmse::SplitB3>"),
+        MFMA16_PEAK_TFLOPS / 6, "dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per multiply", "void sgmse::conv3x3_split_kernel<sgmse::SplitB3, 0, 1, 0"),
     2: ("conv3x3_split_kernel<SplitH2> (3x3 implicit GEMM, fp16x2 operand split, 3 partial products, fp32 accumulate)",
-        MFMA16_PEAK_TFLOPS / 3, "dense f16 MFMA peak 2500 TFLOP/s / 3 partial products per multiply", "void sgmse::conv3x3_split_kernel<sgmse::SplitH2>"),
+        MFMA16_PEAK_TFLOPS / 3, "dense f16 MFMA peak 2500 TFLOP/s / 3 partial products per multiply", "void sgmse::conv3x3_split_kernel<sgmse::SplitH2, 0, 1, 0"),
 }
 HBM_PEAK_GBS = 8000.0
 
@@ -57,7 +57,24 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-evals", type=int, default=8, help="timed CPU score evaluations for the baseline sample")
+    ap.add_argument("--test-emulator", type=str, default=None, metavar="LIB",
+                    help="TEST ONLY (tests/test_host_api.py): run the launcher / collective / reporting logic of this script on CPU "
+                         "tensors with the workgroup-emulator build of the kernels and gloo, reduced-width network; never a measurement")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`bench.py --gpus N` started by hand (no torchrun around it): start the N ranks ourselves, one per GPU, exactly as the
+    driver does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...), and hand their exit code back."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def usable_cpus():
@@ -133,6 +150,8 @@ def hbm_traffic_of_dominant_kernel(prefix):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a))
     wl = {"pc16k": dict(backbone="ncsnpp", sr=16000, sampler="pc", N=30, snr=0.5, batch=32, sde=dict(theta=1.5, sigma_min=0.05, sigma_max=0.5),
                         front=dict(), pad="zero_pad", F=256, flop=FLOP_PER_EVAL, cfg="configs[1]"),
           "ode16k": dict(backbone="ncsnpp", sr=16000, sampler="ode", N=30, snr=0.5, batch=32, sde=dict(theta=1.5, sigma_min=0.05, sigma_max=0.5),
@@ -154,25 +173,39 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: sgmse_amd has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    emu = a.test_emulator is not None
+    if emu:
+        dev = torch.device("cpu")
+        _lib.load_library(a.test_emulator)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: sgmse_amd has no CPU path")
+        if local >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        _lib.load_library()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    _lib.load_library()
+        if emu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)       # "nccl" is RCCL on ROCm
 
     L = int(a.seconds * wl["sr"])
     torch.manual_seed(0)
-    model = ScoreModel(wl["backbone"], "ouve", N=a.N, sr=wl["sr"], **wl["sde"], **wl["front"])   # full-size network, random init
+    sync = (lambda: None) if emu else torch.cuda.synchronize
+    net_kw = dict(nf=32) if emu else {}                                                    # full-size network unless --test-emulator
+    model = ScoreModel(wl["backbone"], "ouve", N=a.N, sr=wl["sr"], **wl["sde"], **wl["front"], **net_kw)   # random init
     model.to(dev).eval()
     bcast_ms = None
     if world > 1:
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         broadcast_backbone_weights(model.dnn, src=0)
-        torch.cuda.synchronize()
+        sync()
         bcast_ms = (time.perf_counter() - t0) * 1e3
 
     g = torch.Generator().manual_seed(1000 + rank)
@@ -185,8 +218,8 @@ def main():
 
     def fence():
         if world > 1:
-            dist.barrier(device_ids=[local])
-        torch.cuda.synchronize()
+            dist.barrier(**({} if emu else {"device_ids": [local]}))
+        sync()
 
     nfe = 0
     for i in range(a.warmup):
@@ -197,10 +230,13 @@ def main():
         x_hat, nfe = step(a.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank = [float(t.item()) for t in every]
+        elapsed = max(per_rank)                               # the job is done when its slowest rank is
     assert torch.isfinite(x_hat).all()
 
     out = None
@@ -230,9 +266,15 @@ def main():
             "path_tflops": a.batch * a.steps * nfe * flop_eval / elapsed / 1e12,
             "path_frac_of_fp32_peak": a.batch * a.steps * nfe * flop_eval / elapsed / 1e12 / FP32_PEAK_TFLOPS,
         }
-        if bcast_ms is not None:
+        out["graph_captures_rank0"] = model.dnn.engine(dev).graph_captures()   # 1: the seed changes per step, the captured step does not
+        if world > 1:
             out["weight_broadcast_ms"] = bcast_ms
-        if not a.no_profile:
+            out["per_rank_utt_per_s"] = [a.batch * a.steps / t for t in per_rank]
+            out["collective_backend"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                         "note": "the only collective: one weight broadcast before the timed region"}
+        if emu:
+            out["data"] = "TEST ONLY: CPU workgroup emulator, reduced-width network -- not a measurement"
+        if not a.no_profile and not emu:
             Y = torch.randn(a.batch, 2, wl["F"], T, dtype=torch.complex64, device=dev) * 0.3
             tt = torch.full((a.batch,), 0.5, device=dev)
             ctx = model.dnn.engine(dev)
@@ -253,11 +295,11 @@ def main():
                 classes[k] = {"ms": round(v["ms"], 3), "launches": v["launches"],
                               ("tflops" if v["unit"] == "flop" else "gbps"): rate / (1e12 if v["unit"] == "flop" else 1e9)}
             out["kernel_classes_one_eval"] = classes
-        if not a.no_cpu_baseline and world == 1 and a.workload == "pc16k":
+        if not a.no_cpu_baseline and world == 1 and a.workload == "pc16k" and not emu:
             out["cpu_baseline"] = cpu_baseline(model.dnn.state_dict(), a.cpu_evals, a.N, a.snr)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local])
+        dist.barrier(**({} if emu else {"device_ids": [local]}))
         dist.destroy_process_group()
 
 

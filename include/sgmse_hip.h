@@ -161,6 +161,12 @@ int sgmse_profile_forward(sgmse_ctx* ctx, const void* xy, const float* t, void* 
 int sgmse_bench_conv(sgmse_ctx* ctx, int ks, int B, int Cin, int Cout, int H, int W, int variant, int iters, int fused,
                      float* ms);
 int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out);
+/* Noise-stream ids (host array, one per utterance) for the NEXT sgmse_pc_sample / sgmse_sb_sample call of batch size n with
+ * in-kernel (Philox) noise: an utterance's draws depend on (seed, stream id, element index inside the utterance, draw index)
+ * only, so with ids that name the utterance its noise does not depend on batch composition or slot.  Default (no call, or a
+ * different batch size): utterance b uses stream b.  Replaces nothing in the reference (torch.randn_like draws depend on the
+ * global generator state, sdes.py:229, correctors.py:74, predictors.py:62). */
+int sgmse_set_noise_streams(sgmse_ctx* ctx, const unsigned long long* ids, int n);
 /* how many times this context captured + instantiated a sampler step as a hipGraph (a run over many batches of one shape and
  * sampler configuration captures once: the Philox seed is device data, not a graph parameter) */
 int sgmse_graph_captures(sgmse_ctx* ctx, int* out);

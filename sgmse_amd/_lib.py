@@ -70,6 +70,7 @@ _SIGS = {
     "sgmse_bench_conv": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "sgmse_arena_bytes": (_I, [_P, C.POINTER(_LL)]),
     "sgmse_graph_captures": (_I, [_P, C.POINTER(_I)]),
+    "sgmse_set_noise_streams": (_I, [_P, C.POINTER(C.c_ulonglong), _I]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -246,7 +247,7 @@ class Context:
 
     def pc_sample(self, Y: torch.Tensor, table: Dict[str, torch.Tensor], *, theta: float, std1: float,
                   corrector: str, corrector_steps: int, predictor: str, probability_flow: bool, denoise: bool,
-                  noise: Optional[torch.Tensor], seed: int, use_graph: bool = True, affine=None, snr: float = 0.0):
+                  noise: Optional[torch.Tensor], seed: int, use_graph: bool = True, affine=None, snr: float = 0.0, streams=None):
         """``affine``: optional (in_scale, score_alpha, score_beta) fp32 tensors of length N: the score wrapper of
         ScoreModel.forward's new-code branch (ncsnpp_v2); None = old-code branch (score = -F)."""
         Y = check_tensor(Y, "y", torch.complex64, self.device)
@@ -280,6 +281,10 @@ class Context:
                 raise ValueError(f"noise must be [{need},{B},1,{F_},{T}] complex64, got {tuple(noise.shape)}")
         out = torch.empty_like(Y)
         nfe = _I(0)
+        if streams is not None:
+            if len(streams) != B:
+                raise ValueError(f"streams must name the {B} utterances of the batch, got {len(streams)}")
+            self.set_noise_streams(streams)
 
         def run():
             self.use_current_stream()
@@ -302,7 +307,7 @@ class Context:
         return out, nfe.value
 
     def sb_sample(self, Y: torch.Tensor, table: Dict[str, torch.Tensor], *, stochastic: bool, noise: Optional[torch.Tensor],
-                  seed: int, affine=None, use_graph: bool = True):
+                  seed: int, affine=None, use_graph: bool = True, streams=None):
         """Schroedinger-bridge sampler; table: fp32 tensors t, w_prev, w_est, w_y, w_z of length N."""
         Y = check_tensor(Y, "y", torch.complex64, self.device)
         B, _, F_, T = Y.shape
@@ -318,6 +323,10 @@ class Context:
                 raise ValueError(f"noise must be [{N},{B},1,{F_},{T}] complex64, got {tuple(noise.shape)}")
         out = torch.empty_like(Y)
         nfe = _I(0)
+        if streams is not None:
+            if len(streams) != B:
+                raise ValueError(f"streams must name the {B} utterances of the batch, got {len(streams)}")
+            self.set_noise_streams(streams)
 
         def run():
             self.use_current_stream()
@@ -363,6 +372,12 @@ class Context:
         out = C.c_int(0)
         self.check(self.lib.sgmse_conv_split_mode(self.h, C.byref(out)))
         return out.value
+
+    def set_noise_streams(self, ids) -> None:
+        """Noise-stream ids (one per utterance) for the next sampler call with in-kernel noise: see sgmse_set_noise_streams."""
+        ids = [int(v) & (2 ** 64 - 1) for v in (ids.tolist() if hasattr(ids, "tolist") else ids)]
+        arr = (C.c_ulonglong * len(ids))(*ids)
+        self.check(self.lib.sgmse_set_noise_streams(self.h, arr, len(ids)))
 
     def graph_captures(self) -> int:
         """Number of hipGraph captures (+ instantiations) of a sampler step this context has done."""

@@ -200,6 +200,11 @@ int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out) {
   return sg_guard(ctx, [&](sgmse::Engine& e) { *out = (long long)e.arena_bytes(); });
 }
 
+int sgmse_set_noise_streams(sgmse_ctx* ctx, const unsigned long long* ids, int n) {
+  SG_ARG(ctx, (ids != nullptr && n > 0) || n == 0, "bad stream table");
+  return sg_guard(ctx, [&](sgmse::Engine& e) { e.set_noise_streams(ids, n); });
+}
+
 int sgmse_graph_captures(sgmse_ctx* ctx, int* out) {
   SG_ARG(ctx, out != nullptr, "out is null");
   return sg_guard(ctx, [&](sgmse::Engine& e) { *out = e.graph_captures(); });

@@ -407,7 +407,7 @@ class Engine {
     SG_CHECK(drt::memcpy_d2d(sy_, Y, n * 8, stream_));   // engine-owned copy: the captured graph never refers to caller memory
     Y = sy_;
     SamplerArgs sa{};
-    sa.x = sx_; sa.x_mean = sxm_; sa.y = Y; sa.score = sscore_; sa.noise = noise; sa.seed = set_seed(seed);
+    sa.x = sx_; sa.x_mean = sxm_; sa.y = Y; sa.score = sscore_; sa.noise = noise; sa.seed = set_seed(seed, B);
     sa.table = step_table_; sa.step_ptr = step_ctr_; sa.theta = sc.theta; sa.std1 = sc.std1; sa.n = (int)n;
     sa.score_w = sc.probability_flow ? 0.5f : 1.0f;
     sa.snr = sc.snr; sa.B = B; sa.per = F * T; sa.partial = lang_partial_; sa.lang = lang_scal_;
@@ -495,8 +495,8 @@ class Engine {
     DRT_LAUNCH(step_set_kernel, dim3(1), dim3(64), stream_, step_ctr_, 0);
 
     SamplerArgs sa{};
-    sa.x = sx_; sa.x_mean = sxm_; sa.y = sy_; sa.score = sscore_; sa.noise = noise; sa.seed = set_seed(seed);
-    sa.table = step_table_; sa.step_ptr = step_ctr_; sa.n = (int)n; sa.add_noise = stochastic ? 1 : 0;
+    sa.x = sx_; sa.x_mean = sxm_; sa.y = sy_; sa.score = sscore_; sa.noise = noise; sa.seed = set_seed(seed, B);
+    sa.table = step_table_; sa.step_ptr = step_ctr_; sa.n = (int)n; sa.add_noise = stochastic ? 1 : 0; sa.B = B; sa.per = F * T;
     sa.draw_base = 0; sa.draw_per_step = 1;
     const dim3 eg((unsigned)((n + 255) / 256));
     FwdCtl ctl{bias_table_, 0, tot_temb_, step_ctr_, tsteps_, 0, 1, -1.0f};
@@ -525,6 +525,7 @@ class Engine {
     SG_CHECK(drt::memcpy_d2d(out, sx_, n * 8, stream_));
     nfe_ = N;
   }
+  void set_noise_streams(const unsigned long long* ids, int n) { streams_next_.assign(ids, ids + n); }
   int last_nfe() const { return nfe_; }
   int graph_captures() const { return graph_captures_; }     // how many times a step was captured + instantiated (tests, bench)
   int split_mode() const { return split_mode_; }
@@ -1348,14 +1349,23 @@ class Engine {
              noise == o.noise && theta == o.theta && dps == o.dps;
     }
   };
-  const unsigned long long* set_seed(unsigned long long seed) {
-    if (!seed_dev_) seed_dev_ = static_cast<unsigned long long*>(dev_alloc(256));
-    seed_host_ = seed;
-    SG_CHECK(drt::memcpy_h2d(seed_dev_, &seed_host_, 8, stream_));
+  // seed word + one noise-stream id per utterance (SamplerArgs::seed); ids given by set_noise_streams are consumed by the next
+  // sampler call of the same batch size, otherwise utterance b gets stream b
+  const unsigned long long* set_seed(unsigned long long seed, int B) {
+    SG_REQUIRE(B + 1 <= kMaxStreams, "batch too large for the noise-stream table");
+    if (!seed_dev_) seed_dev_ = static_cast<unsigned long long*>(dev_alloc((size_t)kMaxStreams * 8));
+    seed_host_.assign((size_t)B + 1, 0ull);
+    seed_host_[0] = seed;
+    const bool given = (int)streams_next_.size() == B;
+    for (int b = 0; b < B; ++b) seed_host_[1 + b] = given ? streams_next_[b] : (unsigned long long)b;
+    streams_next_.clear();
+    SG_CHECK(drt::memcpy_h2d(seed_dev_, seed_host_.data(), seed_host_.size() * 8, stream_));
     SG_CHECK(drt::stream_sync(stream_));
     return seed_dev_;
   }
-  unsigned long long* seed_dev_ = nullptr; unsigned long long seed_host_ = 0;
+  static constexpr int kMaxStreams = 4096;
+  std::vector<unsigned long long> streams_next_;
+  unsigned long long* seed_dev_ = nullptr; std::vector<unsigned long long> seed_host_;
   int graph_captures_ = 0;
 
   int device_;

@@ -276,8 +276,8 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
 }
 
 // complex standard normal (Re, Im ~ N(0, 1/2)), what torch.randn_like gives for complex64
-__device__ __forceinline__ float2 philox_cnormal(unsigned long long seed, unsigned long long idx, uint32_t draw) {
-  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = draw, c3 = 0x5367534du;
+__device__ __forceinline__ float2 philox_cnormal(unsigned long long seed, unsigned long long idx, uint32_t draw, uint32_t stream = 0) {
+  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32) ^ (stream * 0x9E3779B9u), c2 = draw, c3 = 0x5367534du ^ stream;
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
@@ -292,7 +292,11 @@ __device__ __forceinline__ float2 philox_cnormal(unsigned long long seed, unsign
 struct SamplerArgs {
   float2* x; float2* x_mean; const float2* y; const float2* score;
   const float2* noise;       // replayed noise [ndraws][B*FT] or null (Philox)
-  const unsigned long long* seed;   // device word: the Philox seed is data, not a kernel argument, so a captured step serves every seed
+  // device words: seed[0] = the Philox seed (data, not a kernel argument, so a captured step serves every seed), seed[1 + b] =
+  // the noise-stream id of utterance b.  An utterance's draws depend on (seed, stream id, element index INSIDE the utterance,
+  // draw): with stream ids that name the utterance (the directory script: index in the file list) its noise, and with it the
+  // enhanced file, does not depend on how the corpus was batched or sharded.  Default stream id: the batch slot.
+  const unsigned long long* seed;
   const float* table; const int* step_ptr;
   int draw_base, draw_per_step;  // draw index = draw_base + step*draw_per_step
   float theta, score_w;     // score_w: 1 (reverse SDE) or 0.5 (probability flow)
@@ -307,7 +311,8 @@ struct SamplerArgs {
 
 __device__ __forceinline__ float2 sampler_noise(const SamplerArgs& p, int i, int draw) {
   if (p.noise) return p.noise[(size_t)draw * p.n + i];
-  return philox_cnormal(*p.seed, (unsigned long long)i, (uint32_t)draw);
+  const int b = i / p.per;
+  return philox_cnormal(p.seed[0], (unsigned long long)(i - b * p.per), (uint32_t)draw, (uint32_t)p.seed[1 + b]);
 }
 
 __global__ __launch_bounds__(256) void sampler_prior_kernel(SamplerArgs p) {

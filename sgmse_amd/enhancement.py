@@ -5,11 +5,14 @@
 
 Differences from the reference script, none of them in the arithmetic of one utterance:
 
-* files of equal length are enhanced together in batches of up to ``--batch_size``: utterances never interact -- the
-  network and sampler arithmetic of an utterance is bit-identical in any batch (``test_full_size_batch_independence``),
-  only its noise draws depend on its slot -- whereas the reference loops over files one by one (``enhancement.py:57``);
+* files whose PADDED spectrograms have the same number of frames (``pad_spec``: next multiple of 64, i.e. 0.5 s steps at
+  16 kHz) are enhanced together in batches of up to ``--batch_size``, each after its own STFT and padding: utterances never
+  interact -- the network and sampler arithmetic of an utterance is bit-identical in any batch
+  (``test_full_size_batch_independence``), only its noise draws depend on its slot -- whereas the reference loops over files
+  one by one (``enhancement.py:57``);
 * under ``torchrun`` every rank takes a contiguous shard of the sorted file list (the split of the reference's validation
-  loop, ``model.py:212-223``); there is no collective on the data path;
+  loop, ``model.py:212-223``), rank 0 reads the checkpoint and the weights reach the other ranks in one RCCL broadcast; there
+  is no collective on the data path;
 * audio I/O uses ``soundfile`` when it is installed and ``scipy.io.wavfile`` (wav only) otherwise; resampling to the
   model's rate uses ``scipy.signal.resample_poly`` (the reference: ``librosa.resample``).
 """
@@ -76,52 +79,95 @@ def model_audio_settings(model: ScoreModel) -> Tuple[int, str]:
     return 16000, "zero_pad"
 
 
-def build_sampler(model: ScoreModel, Y: torch.Tensor, args, seed=None):
+def build_sampler(model: ScoreModel, Y: torch.Tensor, args, seed=None, streams=None):
     """Sampler dispatch of ``enhancement.py:77-94``.  ``seed``: base of the in-kernel Philox noise stream (None: drawn from
-    torch's generator, like the reference's unseeded ``randn_like``)."""
+    torch's generator, like the reference's unseeded ``randn_like``); ``streams``: per-utterance noise-stream ids."""
     sde = model.sde.__class__.__name__
     if sde == "OUVESDE":
         if args.sampler_type == "pc":
             return model.get_pc_sampler("reverse_diffusion", args.corrector, Y, N=args.N, corrector_steps=args.corrector_steps,
-                                        snr=args.snr, seed=seed)
+                                        snr=args.snr, seed=seed, streams=streams)
         if args.sampler_type == "ode":
-            return model.get_ode_sampler(Y, N=args.N, seed=seed)
+            return model.get_ode_sampler(Y, N=args.N, seed=seed, streams=streams)
         raise ValueError(f"Sampler type {args.sampler_type} not supported")
     if sde == "SBVESDE":
         return model.get_sb_sampler(sde=model.sde, y=Y, sampler_type="ode" if args.sampler_type == "pc" else args.sampler_type,
-                                    seed=seed)
+                                    seed=seed, streams=streams)
     raise ValueError(f"SDE {sde} not supported")
 
 
-def enhance_files(model: ScoreModel, files: List[str], test_dir: str, enhanced_dir: str, args, device) -> int:
+def _load_normalised(path: str, target_sr: int) -> Tuple[torch.Tensor, float]:
+    """File -> peak-normalised mono waveform at the model's rate and its peak (enhancement.py:62-72)."""
+    y, sr = read_audio(path)
+    if sr != target_sr:
+        from scipy.signal import resample_poly
+        g = gcd(sr, target_sr)
+        y = resample_poly(y, target_sr // g, sr // g).astype(np.float32)
+    peak = float(np.abs(y).max()) or 1.0
+    return torch.from_numpy(y / peak), peak
+
+
+def enhance_files(model: ScoreModel, files: List[str], test_dir: str, enhanced_dir: str, args, device, first_index: int = 0) -> int:
+    """Enhance ``files`` in batches.  What has to agree inside a batch is the PADDED spectrogram shape, not the waveform
+    length: every utterance goes through its own STFT and its own ``pad_spec`` (zero / reflection padding to the next multiple
+    of 64 frames, exactly what the reference does per file), utterances with the same padded frame count are stacked, sampled
+    together and inverted one by one with their own lengths.  A corpus of mixed lengths therefore runs in batches (64 frames =
+    0.5 s at 16 kHz granularity) while every utterance keeps the arithmetic of its single-file run bit for bit.  With ``--seed``
+    the noise of an utterance is a function of (seed, its index in the sorted file list): the enhanced files do not depend on
+    the batch size, the bucket an utterance landed in or the number of ranks."""
     target_sr, pad_mode = model_audio_settings(model)
-    # load, resample, normalise (enhancement.py:62-72) and bucket by length
-    buckets: Dict[int, List[Tuple[str, torch.Tensor, float, int]]] = {}
-    for path in files:
-        y, sr = read_audio(path)
-        if sr != target_sr:
-            from scipy.signal import resample_poly
-            g = gcd(sr, target_sr)
-            y = resample_poly(y, target_sr // g, sr // g).astype(np.float32)
-        norm = float(np.abs(y).max()) or 1.0
-        name = path.replace(test_dir, "")
-        name = name[1:] if name.startswith("/") else name
-        buckets.setdefault(len(y), []).append((name, torch.from_numpy(y / norm), norm, len(y)))
+    hop = model.data_module.hop_length
+    by_frames: Dict[int, List[str]] = {}
+    lengths: Dict[str, int] = {}
+    for path in files:                                   # pass 1: lengths only (headers would do; files are small)
+        y, _ = _load_normalised(path, target_sr)
+        lengths[path] = len(y)
+        frames = len(y) // hop + 1
+        by_frames.setdefault((frames + 63) // 64 * 64, []).append(path)
+    index = {path: first_index + k for k, path in enumerate(files)}
     done = 0
-    nbatch = 0
-    for length, items in sorted(buckets.items()):
-        for i in range(0, len(items), args.batch_size):
-            chunk = items[i:i + args.batch_size]
-            seed = None if args.seed is None else args.seed + 1000003 * nbatch
-            nbatch += 1
-            y = torch.stack([c[1] for c in chunk]).to(device)                     # [B, L], equal length
-            Y = pad_spec(model._forward_transform(model._stft(y)).unsqueeze(1), mode=pad_mode)
-            sample, _ = build_sampler(model, Y, args, seed)()
-            x_hat = model.to_audio(sample[:, 0], length).cpu().numpy()            # spec_back + iSTFT (enhancement.py:99)
-            for (name, _, norm, _), x in zip(chunk, x_hat):
-                write_audio(join(enhanced_dir, name), x * norm, target_sr)        # renormalise (enhancement.py:102)
+    for t_pad, paths in sorted(by_frames.items()):
+        for i in range(0, len(paths), args.batch_size):
+            chunk = paths[i:i + args.batch_size]
+            specs, peaks = [], []
+            for path in chunk:
+                y, peak = _load_normalised(path, target_sr)
+                Y = model._forward_transform(model._stft(y[None].to(device))).unsqueeze(1)      # [1,1,F,frames]
+                specs.append(pad_spec(Y, mode=pad_mode))
+                peaks.append(peak)
+            sample, _ = build_sampler(model, torch.cat(specs), args, args.seed, [index[p] for p in chunk])()
+            for j, path in enumerate(chunk):
+                x = model.to_audio(sample[j:j + 1, 0], lengths[path])[0].cpu().numpy()          # spec_back + iSTFT (enhancement.py:99)
+                name = path.replace(test_dir, "")
+                name = name[1:] if name.startswith("/") else name
+                write_audio(join(enhanced_dir, name), x * peaks[j], target_sr)                  # renormalise (enhancement.py:102)
                 done += 1
     return done
+
+
+def load_model(ckpt: str, device, rank: int, world: int) -> ScoreModel:
+    """Single process: read the checkpoint.  Several ranks with an initialised process group: rank 0 reads it (and swaps the
+    EMA weights in), the others build the same architecture from the broadcast hyper-parameters and receive the weights in
+    ONE broadcast over RCCL/xGMI (parallel.broadcast_backbone_weights) -- the only collective of the job."""
+    import torch.distributed as dist
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        model = ScoreModel.load_from_checkpoint(ckpt, map_location=device)
+        model.eval()
+        return model
+    from .parallel import broadcast_backbone_weights
+    box = [None]
+    if rank == 0:
+        model = ScoreModel.load_from_checkpoint(ckpt, map_location=device)
+        model.eval()                                                 # EMA weights in, before they are broadcast
+        box[0] = dict(model.hparams)
+    dist.broadcast_object_list(box, src=0)
+    if rank != 0:
+        model = ScoreModel(**box[0])
+        model._error_loading_ema = True                              # nothing to swap: the received weights ARE the EMA weights
+        model.eval()
+        model.to(device)
+    broadcast_backbone_weights(model.dnn, src=0)
+    return model
 
 
 def main(argv=None) -> int:
@@ -143,17 +189,26 @@ def main(argv=None) -> int:
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = torch.device(args.device)
     if device.type == "cuda":
-        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        if device.index is None:                                     # plain "cuda": one GPU per rank under torchrun
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(device)
-    model = ScoreModel.load_from_checkpoint(args.ckpt, map_location=device)      # every rank reads the checkpoint itself
+    import torch.distributed as dist
+    started_pg = False
+    if world > 1 and dist.is_available() and not dist.is_initialized() and os.environ.get("MASTER_PORT"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if device.type == "cuda" else "gloo", rank=rank, world_size=world)
+        started_pg = True
+    model = load_model(args.ckpt, device, rank, world)
     model.t_eps = args.t_eps
-    model.eval()
     model.to(device)
 
     files = list_audio(args.test_dir)
     lo, hi = shard_range(len(files), rank, world)
-    n = enhance_files(model, files[lo:hi], args.test_dir, args.enhanced_dir, args, device)
+    n = enhance_files(model, files[lo:hi], args.test_dir, args.enhanced_dir, args, device, first_index=lo)
     print(f"[rank {rank}/{world}] enhanced {n} of {len(files)} files into {args.enhanced_dir}")
+    if started_pg:
+        dist.barrier()
+        dist.destroy_process_group()
     return n
 
 

@@ -226,43 +226,44 @@ class ScoreModel(nn.Module):
         return gamma, flat(alpha), flat(beta)
 
     # -- samplers (reference model.py:348-390) -----------------------------------------------------------------
-    def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, **kwargs):
-        N = self.sde.N if N is None else N
-        sde = self.sde.copy()
-        sde.N = N
-        kwargs = {"eps": self.t_eps, **kwargs}
-        if minibatch is None:
-            return sampling.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y, **kwargs)
-        M = y.shape[0]
+    @staticmethod
+    def _minibatch_kwargs(kwargs, lo, hi):
+        """Sampler keyword arguments of the serial chunk [lo, hi) of a batch: replayed noise and noise-stream ids are per
+        utterance; without explicit stream ids a chunk's utterances keep the ids they have in the whole batch (their position),
+        so that chunked and unchunked runs of one seed draw the same noise."""
+        kw = dict(kwargs)
+        if kw.get("noise") is not None:
+            kw["noise"] = kw["noise"][:, lo:hi].contiguous()
+        kw["streams"] = list(range(lo, hi)) if kw.get("streams") is None else list(kw["streams"][lo:hi])
+        return kw
 
+    def _chunked(self, make_sampler, y, minibatch, kwargs):
+        """``minibatch`` wrapper of reference model.py:356-368 / 378-390: the batch in serial chunks, samples concatenated and
+        the chunks' nfe collected in a list."""
         def batched_sampling_fn():
             samples, ns = [], []
-            for i in range(int(ceil(M / minibatch))):
-                y_mini = y[i * minibatch:(i + 1) * minibatch]
-                sample, n = sampling.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y_mini, **kwargs)()
+            for lo in range(0, y.shape[0], minibatch):
+                hi = min(lo + minibatch, y.shape[0])
+                sample, n = make_sampler(y[lo:hi], self._minibatch_kwargs(kwargs, lo, hi))()
                 samples.append(sample)
                 ns.append(n)
             return torch.cat(samples, dim=0), ns
         return batched_sampling_fn
 
-    def get_ode_sampler(self, y, N=None, minibatch=None, **kwargs):
-        N = self.sde.N if N is None else N
+    def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, **kwargs):
         sde = self.sde.copy()
-        sde.N = N
+        sde.N = self.sde.N if N is None else N
         kwargs = {"eps": self.t_eps, **kwargs}
-        if minibatch is None:
-            return sampling.get_ode_sampler(sde, self, y=y, **kwargs)
-        M = y.shape[0]
+        make = lambda yy, kw: sampling.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=yy, **kw)
+        return make(y, kwargs) if minibatch is None else self._chunked(make, y, minibatch, kwargs)
 
-        def batched_sampling_fn():
-            samples, ns = [], []
-            for i in range(int(ceil(M / minibatch))):
-                y_mini = y[i * minibatch:(i + 1) * minibatch]
-                sample, n = sampling.get_ode_sampler(sde, self, y=y_mini, **kwargs)()
-                samples.append(sample)
-                ns.append(n)
-            return torch.cat(samples, dim=0), ns     # (the reference returns only the last mini-batch: model.py:389)
-        return batched_sampling_fn
+    def get_ode_sampler(self, y, N=None, minibatch=None, **kwargs):
+        sde = self.sde.copy()
+        sde.N = self.sde.N if N is None else N
+        kwargs = {"eps": self.t_eps, **kwargs}
+        make = lambda yy, kw: sampling.get_ode_sampler(sde, self, y=yy, **kw)
+        # (with minibatch the reference returns only the LAST chunk's samples, model.py:389; here all of them)
+        return make(y, kwargs) if minibatch is None else self._chunked(make, y, minibatch, kwargs)
 
     def get_sb_sampler(self, sde, y, sampler_type="ode", N=None, **kwargs):
         """reference model.py:392-397 (the passed ``sde`` only supplies the default N; the model's own SDE is used)."""
@@ -324,7 +325,7 @@ class ScoreModel(nn.Module):
         return wave, nfe, (time.time() - t_begin) / (len(wave) / self.sr)
 
     def enhance_batch(self, y, N=30, corrector="ald", corrector_steps=1, snr=0.5, pad_mode="zero_pad", noise=None, seed=None,
-                      predictor="reverse_diffusion", sampler_type="pc", use_graph=True):
+                      predictor="reverse_diffusion", sampler_type="pc", use_graph=True, streams=None):
         """Batched form of enhancement.py:62-99 for B utterances of equal length: y float32 [B, L] on the model's device
         -> enhanced float32 [B, L] (stays on the device).  Not in the reference (which loops files one by one)."""
         dev = self._device()
@@ -335,9 +336,9 @@ class ScoreModel(nn.Module):
         Y = pad_spec(Y, mode=pad_mode)
         if sampler_type == "pc":
             sampler = self.get_pc_sampler(predictor, corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr, noise=noise,
-                                          seed=seed, use_graph=use_graph)
+                                          seed=seed, use_graph=use_graph, streams=streams)
         elif sampler_type == "ode":
-            sampler = self.get_ode_sampler(Y, N=N, noise=noise, seed=seed, use_graph=use_graph)
+            sampler = self.get_ode_sampler(Y, N=N, noise=noise, seed=seed, use_graph=use_graph, streams=streams)
         else:
             raise ValueError(f"Sampler type {sampler_type} not supported")
         sample, nfe = sampler()

@@ -37,12 +37,14 @@ def _native_engine(score_fn, y):
 
 def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=True, eps=3e-2, snr=0.1, corrector_steps=1,
                    probability_flow: bool = False, intermediate=False, noise: Optional[torch.Tensor] = None,
-                   seed: Optional[int] = None, use_graph: bool = True, force_python_loop: bool = False, **kwargs):
+                   seed: Optional[int] = None, use_graph: bool = True, force_python_loop: bool = False, streams=None, **kwargs):
     """Predictor-corrector sampler (reference sampling/__init__.py:26-70).
 
     Extra keyword arguments of this implementation: ``noise`` (complex64 [ndraws,B,1,F,T] replayed standard-normal
     draws in the reference's call order, for bit-comparable runs), ``seed`` (Philox seed when ``noise`` is None;
-    default: drawn from torch's global RNG), ``use_graph``, ``force_python_loop``."""
+    default: drawn from torch's global RNG), ``streams`` (one integer per utterance naming its noise stream: the draws of an
+    utterance then depend on (seed, stream) only, not on its batch slot; default: the slot), ``use_graph``,
+    ``force_python_loop``."""
     predictor_cls = PredictorRegistry.get_by_name(predictor_name)   # ValueError for unknown names, like the reference
     corrector_cls = CorrectorRegistry.get_by_name(corrector_name)
 
@@ -61,7 +63,7 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=Tru
                 out, nfe = ctx.pc_sample(y, table, theta=float(sde.theta), std1=std1, corrector=corrector_name,
                                          corrector_steps=corrector_steps, predictor=predictor_name,
                                          probability_flow=False, denoise=denoise, noise=noise, seed=s, use_graph=use_graph,
-                                         affine=affine, snr=snr)
+                                         affine=affine, snr=snr, streams=streams)
             return out, nfe
         return native_pc_sampler
 
@@ -88,7 +90,7 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=Tru
 
 def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e-5, atol=1e-5, method="RK45", eps=3e-2,
                     device=None, noise: Optional[torch.Tensor] = None, seed: Optional[int] = None, use_graph: bool = True,
-                    **kwargs):
+                    streams=None, **kwargs):
     """Corrector-free probability-flow sampler.
 
     The reference's ``get_ode_sampler`` (sampling/__init__.py:73-143) is an adaptive scipy RK45 that round-trips every
@@ -125,12 +127,12 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
         with torch.no_grad():
             return ctx.pc_sample(y, table, theta=float(sde.theta), std1=std1, corrector="none", corrector_steps=1,
                                  predictor="reverse_diffusion", probability_flow=True, denoise=False, noise=noise, seed=s,
-                                 use_graph=use_graph, affine=affine)
+                                 use_graph=use_graph, affine=affine, streams=streams)
     return ode_sampler
 
 
 def get_sb_sampler(sde, model, y, eps=1e-4, n_steps=50, sampler_type="ode", noise: Optional[torch.Tensor] = None,
-                   seed: Optional[int] = None, use_graph: bool = True, force_python_loop: bool = False, **kwargs):
+                   seed: Optional[int] = None, use_graph: bool = True, force_python_loop: bool = False, streams=None, **kwargs):
     """Schroedinger-bridge samplers (reference sampling/__init__.py:145-249): 'ode' (deterministic) and 'sde'.  With a
     ScoreModel on a HIP backbone the N-step loop runs in the library (sgmse_sb_sample); otherwise the reference-style
     Python loop below.  Returns a zero-argument callable -> (sample, n_steps) like the reference."""
@@ -145,7 +147,7 @@ def get_sb_sampler(sde, model, y, eps=1e-4, n_steps=50, sampler_type="ode", nois
             s = seed if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
             with torch.no_grad():
                 out, _ = ctx.sb_sample(y[:, [0], :, :].contiguous(), table, stochastic=(sampler_type == "sde"), noise=noise, seed=s,
-                                       affine=affine, use_graph=use_graph)
+                                       affine=affine, use_graph=use_graph, streams=streams)
             return out, n_steps
         return native_sb_sampler
 

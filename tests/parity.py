@@ -451,8 +451,9 @@ def check_weight_reload(dev):
 
 
 def check_enhancement_script(dev, tmp_path, monkeypatch):
-    """python -m sgmse_amd.enhancement: checkpoint + directory of wav files -> enhanced directory (batched by length,
-    seeded noise reproducible, rank sharding covers every file exactly once)."""
+    """python -m sgmse_amd.enhancement: checkpoint + directory of wav files of mixed lengths -> enhanced directory (batched by
+    padded frame count; seeded noise is a function of the file, so neither the batch size nor the rank count changes a sample;
+    rank sharding covers every file exactly once)."""
     from scipy.io import wavfile
     from sgmse_amd import enhancement as E
     from sgmse_amd.model import ScoreModel
@@ -477,11 +478,14 @@ def check_enhancement_script(dev, tmp_path, monkeypatch):
         sr, x1 = wavfile.read(str(tmp_path / "o1" / name))
         _, x2 = wavfile.read(str(tmp_path / "o2" / name))
         assert sr == 16000 and x1.shape == (L,) and np.isfinite(x1).all() and np.abs(x1).max() > 0
-        assert np.array_equal(x1, x2)        # same seed, same batching -> same noise -> same waveform
+        assert np.array_equal(x1, x2)        # noise = f(seed, index in the file list): the batch size does not matter
     monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.delenv("MASTER_PORT", raising=False)      # no rendezvous: every rank reads the checkpoint itself
     seen = 0
     with pytest.warns(UserWarning):
         for r in (0, 1):
             monkeypatch.setenv("RANK", str(r))
             seen += E.main(base + ["--enhanced_dir", str(tmp_path / "o3")])
     assert seen == 3 and sorted(str(p.relative_to(tmp_path / "o3")) for p in (tmp_path / "o3").rglob("*.wav")) == sorted(lengths)
+    for name in lengths:                                   # two ranks, other batches: the same samples
+        assert np.array_equal(wavfile.read(str(tmp_path / "o1" / name))[1], wavfile.read(str(tmp_path / "o3" / name))[1])

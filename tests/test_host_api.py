@@ -411,14 +411,17 @@ def test_minibatch_samplers_equal_one_big_batch(emu):
         noise = P.replay_noise(y.shape, 1 + 2 * N)[:, lo:lo + 2].contiguous()
         outs.append(m.get_pc_sampler("reverse_diffusion", "ald", yy, N=N, snr=0.5, noise=noise)()[0])
     assert torch.equal(torch.cat(outs), full)
-    # the minibatch wrapper itself: seeded Philox noise depends on the slot inside a chunk, so compare its structure
+    # the minibatch wrapper itself, in-kernel noise: a chunk's utterances keep the noise-stream ids of their position in the
+    # whole batch, so the chunked run reproduces the unchunked one
+    big, _ = m.get_pc_sampler("reverse_diffusion", "ald", y, N=N, snr=0.5, seed=5)()
     got, ns = m.get_pc_sampler("reverse_diffusion", "ald", y, N=N, snr=0.5, minibatch=2, seed=5)()
-    assert got.shape == y.shape and ns == [2 * N, 2 * N]
-    a, _ = m.get_pc_sampler("reverse_diffusion", "ald", y[:2], N=N, snr=0.5, seed=5)()
-    b, _ = m.get_pc_sampler("reverse_diffusion", "ald", y[2:], N=N, snr=0.5, seed=5)()
-    assert torch.equal(got, torch.cat([a, b]))
+    assert ns == [2 * N, 2 * N] and torch.equal(got, big)
+    # an utterance's noise is a function of (seed, stream id): any slot, any batch
+    perm = [2, 0, 1]
+    moved, _ = m.get_pc_sampler("reverse_diffusion", "ald", y[perm].contiguous(), N=N, snr=0.5, seed=5, streams=perm)()
+    assert torch.equal(moved, big[perm])
     got, ns = m.get_ode_sampler(y, N=2, minibatch=2, seed=5)()
-    assert got.shape == y.shape and ns == [2, 2]
+    assert ns == [2, 2] and torch.equal(got, m.get_ode_sampler(y, N=2, seed=5)()[0])
 
 
 def test_none_predictor_behind_a_corrector_returns_the_noisy_iterate(emu):
@@ -441,3 +444,22 @@ def test_none_predictor_behind_a_corrector_returns_the_noisy_iterate(emu):
     assert nfe == nfe_ref and rel_l2(out, ref) < 1e-4
     out2, _ = m.get_pc_sampler("none", "ald", y, N=N, snr=0.5, noise=noise, use_graph=False)()
     assert torch.equal(out, out2)
+
+
+def test_bench_gpus_2_spawns_two_ranks(emu):
+    """`python bench.py --gpus 2` started WITHOUT torchrun starts its two ranks itself (one per GPU on the GPU box) and rank 0's
+    JSON line says n_gpus = 2, with the weight-broadcast time, per-rank rates and the collective's world size.  Here the ranks
+    run the --test-emulator mode (CPU tensors, gloo, reduced-width network): launcher and reporting logic only."""
+    import json
+    from conftest import EMU_LIB
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SGMSE_EMU_THREADS="4", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "1",
+                          "--seconds", "0.5", "--N", "1", "--test-emulator", EMU_LIB], capture_output=True, text=True, timeout=1500, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout + out.stderr
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["unit"] == "utterances/s"
+    assert d["collective_backend"]["world_size"] == 2 and len(d["per_rank_utt_per_s"]) == 2 and d["weight_broadcast_ms"] > 0
+    assert d["config"]["batch_per_gpu"] == 1 and "TEST ONLY" in d["data"]
+    assert abs(d["value"] - 2 * 1 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
