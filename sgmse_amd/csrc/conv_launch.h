@@ -90,9 +90,25 @@ inline bool conv_thin_split_eligible(int ks, int C1, int C2, int Cout) {
 // mode 1: bf16x3, mode 2: fp16x2 (a.acc_scale must point at the factor stored behind the packed weights)
 // rows4: the 4-row workgroup shape of the full 3x3 kernel (same results; for launches that cannot fill the chip)
 // abl: measurement-only ablation instantiations of the dominant shape (fp16x2, 8 rows, SiLU producer), see the kernel
+// SGMSE_SPLIT_BLK: register blocking of the split 3x3 kernel's waves (kernels_conv_split.h, BLK): 0 = 1 x 8, 1 = 2 x 4 fragments
+#ifndef SGMSE_SPLIT_BLK_DEFAULT
+#define SGMSE_SPLIT_BLK_DEFAULT 0
+#endif
+inline int split_blk() {
+  static int v = [] { const char* e = getenv("SGMSE_SPLIT_BLK"); return e ? atoi(e) : SGMSE_SPLIT_BLK_DEFAULT; }();
+  return v;
+}
 template <class S, int SHAPE>
 inline void launch_conv3x3_split_t(const ConvArgs& a, dim3 grid, drt::stream_t st) {
-  if (a.in_scale && a.in_act) DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1>), grid, dim3(256), st, a);
+  const bool act = a.in_scale && a.in_act;
+  if constexpr (SHAPE == 0) {
+    if (split_blk() == 1) {
+      if (act) DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1, 0, 1>), grid, dim3(256), st, a);
+      else DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 0, 0, 1>), grid, dim3(256), st, a);
+      return;
+    }
+  }
+  if (act) DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1>), grid, dim3(256), st, a);
   else DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 0>), grid, dim3(256), st, a);
 }
 inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t st, bool rows4 = false, int abl = 0) {

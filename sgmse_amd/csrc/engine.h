@@ -342,6 +342,7 @@ class Engine {
       SG_CHECK(drt::stream_sync(stream_));
       for (float v : host) { if (is_w) gmax = std::max(gmax, std::fabs(v)); else bmax = std::max(bmax, std::fabs(v)); }
     }
+    gn_gamma_max_ = gmax; gn_beta_max_ = bmax;
     if (!(gmax <= kH2GammaLimit && bmax <= kH2BetaLimit)) {      // also catches NaN
       split_mode_ = 1;
       fprintf(stderr, "sgmse: GroupNorm affine parameters out of the fp16x2 kernel's guaranteed range (max|gamma| = %g, max|beta| = %g): "
@@ -349,6 +350,14 @@ class Engine {
     }
   }
   static constexpr float kH2GammaLimit = 4.0f, kH2BetaLimit = 64.0f;    // 724 * 4 + 64 < 4094
+  float gn_gamma_max_ = 0.f, gn_beta_max_ = 0.f;
+  double gn_group_max_ = 0.0;        // largest GroupNorm group (elements) of the forward at the current shape, from the dry run
+  // The load-time limits above presume groups of at most 724^2 elements (8 channels x 256 x 256 frames).  Longer utterances
+  // have larger groups (T = 512: 2^20 elements at the full-resolution up-path blocks), so the bound is re-checked against the
+  // ACTUAL group size when the shape is known: sqrt(N) max|gamma| + max|beta| must stay below 65504 / 2^4.
+  bool fp16x2_bound_holds() const {
+    return (std::sqrt(gn_group_max_) * (double)gn_gamma_max_ + (double)gn_beta_max_) * (double)kH2XScale < 65504.0;
+  }
 
   size_t param_count() const { size_t n = 0; for (auto& kv : param_manifest(cfg_)) n += kv.second; return n; }
 
@@ -936,11 +945,19 @@ class Engine {
     if (B != shape_B_ || F != shape_F_ || T != shape_T_) {
       invalidate_graph();
       // size the arena by a dry run
-      arena_.measure_mode();
-      dry_ = true;
-      FwdCtl ctl{nullptr, 0, 0, nullptr, nullptr, 0, 0, 1.f};
-      run_forward(nullptr, 0, nullptr, 0, nullptr, B, F, T, ctl);
-      dry_ = false;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        arena_.measure_mode();
+        dry_ = true;
+        gn_group_max_ = 0.0;
+        FwdCtl ctl{nullptr, 0, 0, nullptr, nullptr, 0, 0, 1.f};
+        run_forward(nullptr, 0, nullptr, 0, nullptr, B, F, T, ctl);
+        dry_ = false;
+        if (split_mode_ != 2 || fp16x2_bound_holds()) break;
+        fprintf(stderr, "sgmse: GroupNorm groups of %.0f elements with max|gamma| = %g, max|beta| = %g exceed the fp16x2 kernel's guaranteed "
+                        "range at this utterance length: using the bf16x3 kernels\n", gn_group_max_, gn_gamma_max_, gn_beta_max_);
+        split_mode_ = 1;
+        finalize_weights();              // repack the split layers for the range-free kernels
+      }
       const size_t need = arena_.high_water() + (1 << 20);
       if (need > arena_cap_) {
         if (arena_base_) dev_free_owned(arena_base_);
@@ -1014,6 +1031,7 @@ class Engine {
   // epilogue when it emitted them (Tensor::st), otherwise from one streaming pass over the tensor.
   void gn_coeffs(const Tensor& a, const Tensor* b, const float* gamma, const float* beta, float** sc, float** sh) {
     const int C = a.C + (b ? b->C : 0), HW = a.H * a.W;
+    gn_group_max_ = std::max(gn_group_max_, (double)(C / std::min(C / 4, 32)) * HW);
     const float* st[2] = {a.st, b ? b->st : nullptr};
     int nsub[2] = {a.nsub, b ? b->nsub : 0};
     float* tmp[2] = {nullptr, nullptr};
@@ -1026,6 +1044,7 @@ class Engine {
         tock();
         DRT_LAUNCH(gn_chan_stats_kernel, dim3(B_ * src[k]->C), dim3(256), stream_, (const float*)src[k]->p, (const float*)nullptr,
                    src[k]->C, 0, HW, tmp[k]);
+        if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "gn_chan_stats C=%d @%dx%dx%d", src[k]->C, B_, a.H, a.W);
         tick(TC_GN, 4.0 * B_ * (double)src[k]->C * HW, 1);
       }
     }
@@ -1036,6 +1055,7 @@ class Engine {
       const int G = std::min(C / 4, 32);
       DRT_LAUNCH(gn_finalize_kernel, dim3(G, B_), dim3(256), stream_, st[0], a.C, nsub[0], st[1], b ? b->C : 0, nsub[1], gamma, beta, G,
                  HW, 1e-6f, *sc, *sh);
+      if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "gn_finalize C=%d nsub=%d @%dx%dx%d", C, nsub[0], B_, a.H, a.W);
       tick(TC_GN, 8.0 * B_ * ((double)a.C * nsub[0] + (b ? (double)b->C * nsub[1] : 0.0)), 1);
     }
     for (int k = 0; k < 2; ++k) if (tmp[k]) arena_.release(tmp[k]);
@@ -1125,11 +1145,13 @@ class Engine {
       ca.w = w.oihw;
       ca.stats_out = nullptr;
       launch_conv_direct(ca, w.ks, stream_);
+      if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "conv-direct%dx%d %d->%d @%dx%dx%d", w.ks, w.ks, Cin, w.cout, B_, a.H, a.W);
       tick(TC_DIRECT, fl);
       if (o.st) {
         tock();
         DRT_LAUNCH(gn_chan_stats_kernel, dim3(B_ * w.cout), dim3(256), stream_, (const float*)o.p, (const float*)nullptr, w.cout, 0,
                    a.H * a.W, o.st);
+        if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "gn_chan_stats(direct) C=%d @%dx%dx%d", w.cout, B_, a.H, a.W);
         tick(TC_GN, 4.0 * B_ * (double)w.cout * a.H * a.W, 1);
       }
     }
@@ -1158,6 +1180,7 @@ class Engine {
     FirArgs fa{a.p, o.p, xf.scale, xf.shift, xf.act, B_ * a.C, a.H, a.W, raw ? raw->p : nullptr};
     tock();
     launch_fir(fa, up);
+    if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "fir-%s C=%d @%dx%dx%d%s", up ? "up" : "down", a.C, B_, a.H, a.W, raw ? " +raw" : "");
     tick(TC_FIR, 4.0 * B_ * (double)a.C * (a.H * a.W + (raw ? 2.0 : 1.0) * o.H * o.W));
     return o;
   }
@@ -1212,6 +1235,7 @@ class Engine {
       AttnArgs aa{qkv.p, o.p, B_, x.C, x.H * x.W, 1.0f / sqrtf((float)x.C)};
       tock();
       SG_REQUIRE(launch_attn_core(aa, stream_), "attention: unsupported channel count");
+      if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "attention C=%d S=%d B=%d", x.C, x.H * x.W, B_);
       tick(TC_ATTN, 4.0 * B_ * (double)x.C * (x.H * x.W) * (double)(x.H * x.W));
     }
     drop(qkv);

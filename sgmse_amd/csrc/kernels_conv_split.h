@@ -187,16 +187,22 @@ inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<
 // the first K-stage (no raw loads, producer, LDS writes), 16 B fragments read from LDS once, 32 A fragments loaded once;
 // correct results: 64 phase time stamps per workgroup (ConvArgs::trace), 128 / 256 epilogue variants (conv_epilogue), 512 LDS
 // padded to one workgroup per CU.
-template <class S, int SHAPE = 0, int ACT = 1, int ABL = 0>
+// BLK: register blocking of a wave inside the 128-channel block: 0 = 1 channel fragment x all pixel fragments (B operand
+// read by all four waves, A operand private), 1 = 2 channel fragments x half of the pixel fragments (half the LDS operand
+// reads; each A fragment loaded by two waves; the two channel fragments' MFMAs alternate, so no MFMA waits on its predecessor).
+template <class S, int SHAPE = 0, int ACT = 1, int ABL = 0, int BLK = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   constexpr bool THIN = SHAPE == 1;
   constexpr int ROWS = SHAPE == 2 ? 4 : 8;
   using C = ConvSplitGeom<ROWS>;
-  // epilogue geometry: 4 channel-waves x 1 fragment x ROWS pixel fragments, or 1 channel-wave, 4 pixel-waves x 2 fragments
-  using T = std::conditional_t<THIN, ConvTile<3, 1, 1, 2, 1>, ConvTile<3, 4, 1, ROWS, 1>>;
+  static_assert(!(THIN && BLK), "the thin shape has one channel fragment");
+  constexpr int WCW = THIN ? 1 : (BLK ? 2 : 4);     // waves along the output channels
+  constexpr int FCW = THIN ? 1 : 4 / WCW;           // channel fragments per wave
+  constexpr int FPW = THIN ? 2 : ROWS / (4 / WCW);  // pixel fragments (image rows) per wave
+  // epilogue geometry: WCW channel-waves x FCW fragments, 4 / WCW pixel-waves x FPW fragments
+  using T = ConvTile<3, WCW, FCW, FPW, 1>;
   static_assert(T::CO_T == (THIN ? 32 : 128) && T::ROWS == ROWS, "tile");
   constexpr int NS = S::NS, PX_V = S::PX_V;
-  constexpr int FPW = THIN ? 2 : ROWS;     // pixel fragments per wave
   constexpr int EPJ = 8 / FPW;             // producer elements staged behind each fragment's MFMAs
   constexpr int STAGE_V = C::TROWS * C::TCOLS * PX_V;
   constexpr int DUMMY_V = STAGE_V;         // scratch slot behind the tile for the stores of items outside the image
@@ -340,35 +346,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   };
 
   // accumulators start from (bias + time-embedding row) / acc_scale (conv_acc_init): no bias work in the epilogue
-  f32x16 acc[1][FPW];
-  {
+  const int wc = THIN ? 0 : wave % WCW, wp = THIN ? wave : wave / WCW;     // this wave's channel / pixel position in the block
+  f32x16 acc[FCW][FPW];
+#pragma unroll
+  for (int i = 0; i < FCW; ++i) {
     float init[16];
-    conv_acc_init<T>(p, b, co_blk, THIN ? 0 : wave, kg, 1.0f, init);
+    conv_acc_init<T>(p, b, co_blk, wc * FCW + i, kg, 1.0f, init);
 #pragma unroll
     for (int j = 0; j < FPW; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][j][r] = init[r];
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = init[r];
   }
 
   const int nst = Cin / C::KC;
   // A fragments of this wave: [co_blk][stage][tap][split][wave][lane] (THIN: every wave uses fragment 0); uniform
   // fragment pointer + lane byte offset
   const u32x4* wblk = reinterpret_cast<const u32x4*>(p.w) + (size_t)co_blk * nst * 9 * NS * 4 * 64;
-  const unsigned a_boff = (unsigned)(((THIN ? 0 : wave) * 64 + lane) * 16);
-  auto load_a = [&](int st, int tap, u32x4 (&a)[NS]) {
+  const unsigned a_boff = (unsigned)((wc * FCW * 64 + lane) * 16);
+  auto load_a = [&](int st, int tap, u32x4 (&a)[FCW][NS]) {
     const u32x4* q = wblk + (size_t)(st * 9 + tap) * NS * 4 * 64;
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-      a[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s * 4 * 64) + a_boff);
+    for (int i = 0; i < FCW; ++i)
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        a[i][s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s * 4 * 64 + i * 64) + a_boff);
   };
   // B fragment base of this lane inside a stage buffer (u32x4 units): pixel (row j + dy, col l31 + dx), k-group kg
-  const int b_lane = l31 * PX_V + kg * NS + (THIN ? wave * FPW * C::TCOLS * PX_V : 0);
+  const int b_lane = l31 * PX_V + kg * NS + wp * FPW * C::TCOLS * PX_V;
 
   // one tap of one stage: FPW pixel fragments x NP split products.  The B reads of fragment j+1 are issued before the
   // MFMAs of fragment j (order pinned with sched_barrier: left alone, the compiler sinks every LDS read to just in front
   // of its first use and waits lgkmcnt(0) for each).
   u32x4 bq[2][NS];
-  auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[NS], int item, int c0n, u32x4* nxt) {
+  auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[FCW][NS], int item, int c0n, u32x4* nxt) {
     const int dy = tap / 3, dx = tap - 3 * dy;
     const u32x4* sb = sbuf + b_lane + (dy * C::TCOLS + dx) * PX_V;
     if constexpr (!(ABL & 16)) {
@@ -385,10 +395,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
         }
       }
       __builtin_amdgcn_sched_barrier(SGMSE_SPLIT_FENCE);
-      f32x16 c = acc[0][j];
 #pragma unroll
-      for (int k = 0; k < S::NP; ++k) c = S::mfma(a[S::pa(k)], bq[j & 1][S::pb(k)], c);
-      acc[0][j] = c;
+      for (int k = 0; k < S::NP; ++k)
+#pragma unroll
+        for (int i = 0; i < FCW; ++i) acc[i][j] = S::mfma(a[i][S::pa(k)], bq[j & 1][S::pb(k)], acc[i][j]);
       if (item >= 0) {
 #pragma unroll
         for (int e = 0; e < EPJ; ++e) stage_elem(item, j * EPJ + e, c0n);
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   // latency on every tap (profiles/r02_split_ablation_microbench.txt: staging, fragment loads and the epilogue's memory
   // traffic each ADDED their time to the K loop).  9 taps % 3 == 0: the ring index of a tap is the same in every stage.
   unsigned long long tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // ABL 64: time per tap position and at the stage barrier (wave 0)
-  u32x4 ar[3][NS];
+  u32x4 ar[3][FCW][NS];
   load_a(0, 0, ar[0]);
   load_a(0, 1, ar[1]);
   if constexpr (ABL & 16) {
@@ -461,8 +471,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   }
 
   if constexpr (ABL & 64) { if (trace) trace[3] = drt_clock(); }
-  if constexpr (THIN) conv_epilogue<T, 1, FPW, 1, ABL & 3, true>(p, acc, b, co_blk, tx, ty, tiles_x, 0, wave, l31, kg);
-  else conv_epilogue<T, 1, FPW, 4, ABL & (3 | 128 | 256), true>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg);
+  conv_epilogue<T, FCW, FPW, WCW, ABL & (3 | 128 | 256), true>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg);
   if constexpr (ABL & 64) { if (trace) trace[4] = drt_clock(); }
 }
 

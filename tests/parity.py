@@ -241,6 +241,64 @@ def check_split_workgroup_shapes_bitwise(dev, name="fwd_nf128"):
     assert rel_l2(outs[0], torch.from_numpy(z["out"])) < NET_TOL
 
 
+def adversarial_params(cfg, kind, seed=0):
+    """Synthetic state dicts that stress the range handling of the fp16x2 / bf16x3 kernels (no real checkpoint is reachable
+    offline): every kind must keep the network-level gate of the ordinary fixtures.
+      gn_inside   GroupNorm gamma up to 4 and beta up to 64: just inside the fp16x2 guard (engine.h: kH2GammaLimit / kH2BetaLimit)
+      gn_outside  gamma 4.5 in one module: the model must switch itself to the range-free bf16x3 kernels
+      growth      residual stream growing ~10^3 across the network (Conv_1 and the shortcut of every block scaled up)
+      outliers    a few output channels of some convolutions x 10^4 (heavy-tailed activations)
+      zero_init   Conv_1 of every block at the reference's init_scale=0 magnitude (1e-10, layers.py:88-91): dead branches"""
+    P = synth.synth_params(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 101)
+    res_blocks = sorted({k.rsplit(".", 2)[0] for k in P if k.endswith("Conv_1.weight")}, key=lambda n: int(n.split(".")[1]))
+    if kind in ("gn_inside", "gn_outside"):
+        for k, v in P.items():
+            if "GroupNorm" in k and k.endswith("weight"):
+                v.copy_(1.0 + 3.0 * torch.rand(v.shape, generator=g))                    # [1, 4)
+                v[0] = 4.0
+            elif "GroupNorm" in k and k.endswith("bias"):
+                v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * 64.0)
+        if kind == "gn_outside":
+            P[res_blocks[len(res_blocks) // 2] + ".GroupNorm_1.weight"][3] = 4.5
+    elif kind == "growth":
+        f = 1000.0 ** (1.0 / len(res_blocks))
+        for name in res_blocks:
+            P[name + ".Conv_1.weight"] *= f * 1.6                                         # (x + h) / sqrt(2) keeps ~0.7 of each branch
+            if name + ".Conv_2.weight" in P:
+                P[name + ".Conv_2.weight"] *= f * 1.6
+    elif kind == "outliers":
+        for name in res_blocks[::3]:
+            P[name + ".Conv_1.weight"][:3] *= 1e4
+            P[name + ".Conv_0.weight"][5:7] *= 1e4
+        P["all_modules.3.weight"][:2] *= 1e4
+    elif kind == "zero_init":
+        for name in res_blocks:
+            P[name + ".Conv_1.weight"] *= 1e-10
+    else:
+        raise ValueError(kind)
+    return P
+
+
+def check_adversarial_checkpoint(dev, kind, nf=128, T=64, expect_mode=None):
+    cfg = NO.NetCfg.for_variant("ncsnpp", nf=nf)
+    Pm = adversarial_params(cfg, kind)
+    net, _ = make_backbone(cfg, dev, P=Pm)
+    gx = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 2, 256, T, dtype=torch.complex64, generator=gx) * 0.3
+    t = torch.tensor([0.7, 0.08])
+    with torch.no_grad():
+        ref = NO.ncsnpp_forward(Pm, cfg, x, t)
+    out = net(x.to(dev), t.to(dev))
+    mode = net.engine(torch.device(dev)).conv_split_mode()
+    err = rel_l2(out.cpu(), ref)
+    print(f"adversarial checkpoint '{kind}' (nf={nf}) on {dev}: split mode {mode}, output range {float(ref.abs().max()):.3g}, rel_l2 vs oracle {err:.3e}")
+    assert torch.isfinite(torch.view_as_real(out)).all()
+    if expect_mode is not None:
+        assert mode == expect_mode, (kind, mode)
+    assert err < NET_TOL, (kind, err)
+
+
 def make_model(cfg, dev, P=None, sde="ouve", **kw):
     from sgmse_amd.model import ScoreModel
     P = synth.synth_params(cfg, seed=0) if P is None else P

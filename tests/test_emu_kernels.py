@@ -221,5 +221,9 @@ def test_extreme_groupnorm_parameters_select_the_range_free_kernels(emu, capfd):
     assert net3.engine(torch.device(emu)).conv_split_mode() == 2
 
 
+def test_adversarial_checkpoint_residual_stream_growth(emu):
+    P.check_adversarial_checkpoint(emu, "growth", nf=32, expect_mode=2)
+
+
 def test_enhancement_script_directory_to_directory(emu, tmp_path, monkeypatch):
     P.check_enhancement_script(emu, tmp_path, monkeypatch)

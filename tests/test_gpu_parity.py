@@ -308,6 +308,34 @@ def test_batch_of_four_equals_four_singles_bitwise(hip):
     P.check_batch_equals_singles(hip, 4)
 
 
+@pytest.mark.parametrize("kind,mode", [("gn_inside", 2), ("gn_outside", 1), ("growth", 2), ("outliers", 2), ("zero_init", 2)])
+def test_adversarial_checkpoints_keep_the_network_gate(hip, kind, mode):
+    """Full-width network with synthetic state dicts built to stress the fp16x2 range handling (GroupNorm parameters at and
+    beyond the guard, a residual stream growing 10^3, outlier channels x 10^4, dead Conv_1 branches) against the oracle."""
+    P.check_adversarial_checkpoint(hip, kind, expect_mode=mode)
+
+
+def test_long_utterance_rechecks_the_fp16x2_range_bound(hip, capfd):
+    """The GroupNorm output bound grows with the group size: gamma = 3.9 is inside the load-time guard but 8 channels x 256 x 1024
+    frames exceed the fp16x2 range, so the engine must switch to the bf16x3 kernels when it sees that shape -- and say so."""
+    cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
+    Pm = synth.synth_params(cfg, seed=0)
+    for k, v in Pm.items():
+        if "GroupNorm" in k and k.endswith("weight"):
+            v[0] = 3.9
+    net, _ = P.make_backbone(cfg, hip, P=Pm)
+    g = torch.Generator().manual_seed(5)
+    short = torch.randn(1, 2, 256, 64, dtype=torch.complex64, generator=g) * 0.3
+    net(short.to(hip), torch.tensor([0.5], device=hip))
+    assert net.engine(torch.device(hip)).conv_split_mode() == 2
+    long = torch.randn(1, 2, 256, 2048, dtype=torch.complex64, generator=g) * 0.3
+    out = net(long.to(hip), torch.tensor([0.5], device=hip))
+    assert net.engine(torch.device(hip)).conv_split_mode() == 1 and "utterance length" in capfd.readouterr().err
+    with torch.no_grad():
+        ref = NO.ncsnpp_forward(Pm, cfg, long, torch.tensor([0.5]))
+    assert rel_l2(out.cpu(), ref) < P.NET_TOL
+
+
 def test_full_size_batch_independence(hip):
     """Size-independent property at the bench shape: utterances never interact, so a batched evaluation equals the
     per-utterance evaluations bit for bit, in any batch position."""
