@@ -29,10 +29,10 @@ inline int conv_variant() {
 }
 
 template <int KS, int WC, int FC, int FP>
-inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant) {
+inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant, int ksplit = 1) {
   using T = ConvTile<KS, WC, FC, FP>;
   const int tiles = a.B * ((a.H + T::ROWS - 1) / T::ROWS) * ((a.W + 31) / 32);
-  dim3 grid(tiles, (a.Cout + T::CO_T - 1) / T::CO_T, 1);
+  dim3 grid(tiles, (a.Cout + T::CO_T - 1) / T::CO_T, ksplit);
   if (variant < 0) variant = conv_variant();
   const bool vec = (a.W % 4 == 0) && !(variant & 2) && (reinterpret_cast<uintptr_t>(a.src1) % 16 == 0) &&
                    (a.src2 == nullptr || reinterpret_cast<uintptr_t>(a.src2) % 16 == 0);
@@ -45,9 +45,13 @@ inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant)
   else if (vec) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 1>), grid, dim3(256), st, a);
   else if (pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 0>), grid, dim3(256), st, a);
   else DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 0>), grid, dim3(256), st, a);
+  if constexpr (FC * FP <= 2) {
+    if (ksplit > 1) DRT_LAUNCH((conv_splitk_reduce_kernel<KS, WC, FC, FP>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
+  }
 }
 
-inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1) {
+// ksplit > 1 (small tiles only, ConvArgs::kchunk_stages chunks): split-K over gridDim.z + the reduce/epilogue kernel
+inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1, int ksplit = 1) {
   const int v = variant < 0 ? conv_variant() : variant;
   if (ks == 1 && pl.co_t == 128 && (v & 8)) {
     // streaming kernel chunk: 32 channels, or 64 with bit 4 (one wave = 128 co x 32 px of one row; an 8-row-per-workgroup
@@ -63,7 +67,7 @@ inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt:
     }
   }
 #define SGMSE_CONV_CASE(KS_, CO_, ROWS_, WC_, FC_, FP_) \
-  if (ks == KS_ && pl.co_t == CO_ && pl.rows == ROWS_) { launch_conv_mfma_t<KS_, WC_, FC_, FP_>(a, st, variant); return; }
+  if (ks == KS_ && pl.co_t == CO_ && pl.rows == ROWS_) { launch_conv_mfma_t<KS_, WC_, FC_, FP_>(a, st, variant, ksplit); return; }
   SGMSE_CONV_CASE(3, 128, 8, 2, 2, 4)
   SGMSE_CONV_CASE(3, 64, 8, 2, 1, 4)
   SGMSE_CONV_CASE(3, 32, 8, 1, 1, 2)

@@ -823,7 +823,7 @@ class Engine {
       pa.cout = cout; pa.co_t = pl.co_t; pa.dst = pk; pa.total = ne;
       DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, pa);
       c.packed = pk;
-      if (pl.co_t > 32 && ks == 3) {
+      if (pl.co_t > 32) {
         const size_t ne32 = packed_weight_elems(ks, cin, cout, 32);
         float* pk32 = static_cast<float*>(dev_alloc_w(ne32 * 4));
         PackArgs pb = pa; pb.co_t = 32; pb.dst = pk32; pb.total = ne32;
@@ -1094,6 +1094,25 @@ class Engine {
                         // raw residual stream and scale by the producers' range bounds, which must then be known
                         (w.split_mode != 2 || (w.ks == 3 ? (xf.scale != nullptr || xf.bounded)
                                                          : (xf.scale == nullptr && a.amax && (!b || b->amax))));
+    // Coarse levels (at most 512 pixels per image) on the fp32 kernels: 32-channel tiles with CHUNKED accumulation (decided per
+    // layer and image, never by the batch: it fixes the summation order), and -- when even those tiles leave most CUs idle
+    // (small batches) -- the chunks spread over workgroups (split-K, bit-identical): a K loop of 32-64 serial stages was the
+    // latency of these launches (60-120 us each at batch 1, profiles/r02_prof_dump_b1_per_launch.txt)
+    int kchunk = 0, ksplit = 1;
+    float* partial = nullptr;
+    if (use_mfma && !use_split && coarse_chunked_ && (long)a.H * a.W <= 512 && (w.co_t == 32 || w.packed32)) {
+      co_t = 32;
+      const long nblk8 = (long)B_ * ((a.H + 7) / 8) * ((a.W + 31) / 32) * ((w.cout + 31) / 32);
+      rows_ = (a.H >= 8 && nblk8 >= tile_min_blocks_) ? 8 : 4;
+      const int nstages = Cin / kc_;
+      kchunk = std::max(w.ks == 3 ? 4 : 2, (nstages + 7) / 8);
+      const int nchunks = (nstages + kchunk - 1) / kchunk;
+      const long nblk = (long)B_ * ((a.H + rows_ - 1) / rows_) * ((a.W + 31) / 32) * ((w.cout + 31) / 32);
+      if (nchunks > 1 && nblk * 2 <= tile_min_blocks_) {
+        ksplit = nchunks;
+        partial = arena_.alloc((size_t)nchunks * B_ * w.cout * a.H * a.W);
+      }
+    }
     if (emit_stats && use_mfma && fuse_gn_stats_) {
       o.nsub = conv_plan_nsub(a.H, a.W);
       o.st = arena_.alloc((size_t)B_ * w.cout * o.nsub * 2);
@@ -1104,7 +1123,7 @@ class Engine {
       o.st = arena_.alloc((size_t)B_ * w.cout * 2);
     }
     o.amax = next_amax();
-    if (dry_) return o;
+    if (dry_) { if (partial) arena_.release(partial); return o; }
     ConvArgs ca{};
     ca.stats_out = o.st; ca.stats_nsub = o.nsub;
     ca.amax_out = o.amax;
@@ -1135,10 +1154,12 @@ class Engine {
     } else if (use_mfma) {
       ConvPlan pl{co_t, rows_, true};
       ca.w = (co_t == w.co_t) ? w.packed : w.packed32;
-      launch_conv_mfma(ca, w.ks, pl, stream_);
+      ca.kchunk_stages = kchunk; ca.partial = partial;
+      launch_conv_mfma(ca, w.ks, pl, stream_, -1, ksplit);
+      if (partial) arena_.release(partial);
       if (prof_ && prof_dump_)
-        snprintf(prof_note_, sizeof prof_note_, "conv%dx%d %d->%d @%dx%dx%d tile %dco x %drows%s%s", w.ks, w.ks, Cin, w.cout, B_, a.H, a.W,
-                 co_t, rows_, res ? " +res" : "", xf.scale ? " +gn" : "");
+        snprintf(prof_note_, sizeof prof_note_, "conv%dx%d %d->%d @%dx%dx%d tile %dco x %drows%s%s%s", w.ks, w.ks, Cin, w.cout, B_, a.H, a.W,
+                 co_t, rows_, res ? " +res" : "", xf.scale ? " +gn" : "", ksplit > 1 ? " split-K" : "");
       // class "wide" = the dominant kernel family only: the split kernels, or (SGMSE_CONV_SPLIT=0) the fp32 128 x 256 tile
       tick(w.ks == 3 ? ((split_mode_ == 0 && co_t == 128 && pl.rows == 8) ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else {
@@ -1426,6 +1447,7 @@ class Engine {
     split_stagger_ = e ? atol(e) : SGMSE_SPLIT_STAGGER_DEFAULT;
     e = getenv("SGMSE_SPLIT_STAGGER_MODE");
     split_stagger_mode_ = e ? atoi(e) : 0;
+    coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);   // chunked accumulation (+ split-K) of the coarse levels' fp32 layers
   }
   // per-forward range-bound slots ([B][kAmaxSpread] floats each), handed out in program order; counted by the dry run
   float* amax_pool_ = nullptr; size_t amax_pool_floats_ = 0; int amax_slots_ = 0, amax_next_ = 0;
@@ -1437,6 +1459,7 @@ class Engine {
   }
   long tile_min_blocks_ = 512, split_min_tiles_ = 8, split_stagger_ = SGMSE_SPLIT_STAGGER_DEFAULT;
   int split_stagger_mode_ = 0;
+  bool coarse_chunked_ = true;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};

@@ -10,17 +10,30 @@ namespace sgmse {
 // Attention core of AttnBlockpp (reference layerspp.py:82-88):
 //   w[s,r] = softmax_r( sum_c q[c,s] k[c,r] * C^-1/2 ),  o[c,s] = sum_r w[s,r] v[c,r]
 // qkv: [B][3C][S] (q | k | v along channels, S = H*W contiguous), out: [B][C][S].
-// One workgroup = 32 queries; its 4 waves take key tiles round-robin with private online-softmax state and are
-// merged through LDS at the end.  Both contractions run on v_mfma_f32_32x32x2_f32:
-//   QK^T:  D[i=key][j=query]  A = k[c][key] (lane = key), B = q[c][query] (lane = query)  -> 128-B coalesced loads
+// One workgroup = 32 queries; its 4 waves take 32-key tiles round-robin with private online-softmax state and are merged
+// through LDS at the end.  Both contractions run on v_mfma_f32_32x32x2_f32 (exact fp32):
+//   QK^T:  D[i=key][j=query]  A = k[c][key] (lane = key), B = q[c][query] (lane = query)
 //   P.V :  D[i=chan][j=query]  B operand of k-step r IS accumulator register r of the score fragment
 //          (key(r,kh) = (r&3)+8*(r>>2)+4*kh is exactly the key the lane holds), so P never leaves registers.
+// Operand paths (every global access is a 128-byte row segment; round 1 gathered V with stride S across the lanes and
+// loaded q / k inside the MFMA loop: 9 % of the fp32 MFMA peak):
+//   q: the workgroup's [C][32] tile staged ONCE in LDS, read as the B operand (lane = query: conflict-free);
+//   k: [c][32 keys] rows straight from global memory (lane = key), 16 k-steps (32 channels) in registers, the next 16
+//      loaded while the MFMAs of the current ones run;
+//   v: a wave's [C][32 keys] tile loaded as rows (two rows per wave instruction) one 64-channel chunk ahead, transposed through a
+//      wave-private LDS tile with rows padded to 33 floats (bank = channel + key: conflict-free both ways) in chunks of 64
+//      channels; the A operand of P.V (lane = channel) is then one ds_read_b32.
+// LDS: q 32 KB + 4 x 8.4 KB (C = 256) = 66 KB and at most 256 registers: two workgroups per CU.
 struct AttnArgs { const float* qkv; float* out; int B, C, S; float scale; };
 
 template <int CF>
-__global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnArgs p) {
   constexpr int C = CF * 32;
-  __shared__ float s_O[C * 32];
+  constexpr int FH = CF < 2 ? CF : 2;          // channel fragments per V chunk (64 channels: two workgroups per CU fit)
+  constexpr int NH = CF / FH;                  // V chunks per key tile
+  constexpr int VS = 33;                       // padded row of the transposed V tile
+  __shared__ float s_q[C * 32];                // q tile; reused as the cross-wave output accumulator at the end
+  __shared__ float s_v[4][FH * 32 * VS];
   __shared__ float s_m[4][32];
   __shared__ float s_l[4][32];
   __shared__ float s_lt[32];
@@ -31,8 +44,15 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs p) {
   const float* k = q + (size_t)C * S;
   const float* v = k + (size_t)C * S;
   const int nkt = (S + 31) / 32;
-  const bool qok = (s0 + l31) < S;
   const float NEG_INF = -INFINITY;
+  const drt_buf kbuf = drt_make_buf(k), vbuf = drt_make_buf(v);
+  const unsigned rowb = (unsigned)S * 4u;                          // bytes per channel row
+
+  for (int e = tid; e < C * 32; e += 256) {                       // q tile: rows of 32 queries
+    const int c = e >> 5, j = e & 31;
+    s_q[e] = (s0 + j) < S ? q[(size_t)c * S + s0 + j] : 0.f;
+  }
+  __syncthreads();
 
   float m = NEG_INF, lsum = 0.f;
   f32x16 O[CF];
@@ -40,19 +60,47 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs p) {
   for (int f = 0; f < CF; ++f)
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[f][r] = 0.f;
+  float* sv = s_v[wave];
 
   for (int kt = wave; kt < nkt; kt += 4) {
     const int r0 = kt * 32;
     const bool kok = (r0 + l31) < S;
+    // row (channel 2 i + kh), column (key r0 + l31): one VGPR byte offset per lane + a uniform offset per row pair
+    const unsigned lane_boff = (unsigned)(kh * S + r0 + l31) * 4u;
+    // this wave's V tile: row (channel) 2 i + kh of chunk h, column (key) l31; in flight during the QK^T loop
+    float vreg[FH * 16];
+    auto load_v = [&](int h) {
+#pragma unroll
+      for (int i = 0; i < FH * 16; ++i) vreg[i] = kok ? drt_buf_load(vbuf, lane_boff, (unsigned)(h * FH * 32 + 2 * i) * rowb) : 0.f;
+    };
+    load_v(0);
+
     f32x16 sc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-#pragma unroll 8
-    for (int c2 = 0; c2 < C / 2; ++c2) {
-      const int c = 2 * c2 + kh;
-      const float a = kok ? k[(size_t)c * S + r0 + l31] : 0.f;
-      const float bq = qok ? q[(size_t)c * S + s0 + l31] : 0.f;
-      sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, sc, 0, 0, 0);
+    // k in chunks of 16 k-steps (32 channels), two register sets: the loop is NOT unrolled across chunk pairs, or the compiler
+    // hoists every chunk's loads to the top and spills
+    float ka0[16], ka1[16];
+    auto load_k = [&](int ch, float (&dst)[16]) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dst[i] = kok ? drt_buf_load(kbuf, lane_boff, (unsigned)(ch * 32 + 2 * i) * rowb) : 0.f;
+    };
+    auto qk = [&](int ch, const float (&src)[16]) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        sc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[i], s_q[(ch * 32 + 2 * i + kh) * 32 + l31], sc, 0, 0, 0);
+    };
+    load_k(0, ka0);
+    if constexpr (CF == 1) {
+      qk(0, ka0);
+    } else {
+#pragma unroll 1
+      for (int ch = 0; ch < CF; ch += 2) {
+        load_k(ch + 1, ka1);
+        qk(ch, ka0);
+        if (ch + 2 < CF) load_k(ch + 2, ka0);
+        qk(ch + 1, ka1);
+      }
     }
     float mx = NEG_INF;
 #pragma unroll
@@ -80,19 +128,24 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[f][r] *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      const float bp = sc[r];
+    for (int h = 0; h < NH; ++h) {
+      drt_wave_sync();                                             // the previous chunk's reads are done (wave-private tile)
 #pragma unroll
-      for (int f = 0; f < CF; ++f) {
-        const float a = (key < S) ? v[(size_t)(f * 32 + l31) * S + key] : 0.f;
-        O[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp, O[f], 0, 0, 0);
+      for (int i = 0; i < FH * 16; ++i) sv[(2 * i + kh) * VS + l31] = vreg[i];
+      drt_wave_sync();
+      if (h + 1 < NH) load_v(h + 1);                               // in flight during this chunk's MFMAs
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * kh;
+#pragma unroll
+        for (int f = 0; f < FH; ++f)
+          O[h * FH + f] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[(f * 32 + l31) * VS + key], sc[r], O[h * FH + f], 0, 0, 0);
       }
     }
   }
 
   if (kh == 0) { s_m[wave][l31] = m; s_l[wave][l31] = lsum; }
-  __syncthreads();
+  __syncthreads();                                                 // also: every wave is done with s_q
   float mstar = fmaxf(fmaxf(s_m[0][l31], s_m[1][l31]), fmaxf(s_m[2][l31], s_m[3][l31]));
   const float fac = expf(m - mstar);
   if (wave == 0 && kh == 0) {
@@ -105,6 +158,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs p) {
   for (int f = 0; f < CF; ++f)
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[f][r] *= fac;
+  float* s_O = s_q;
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll

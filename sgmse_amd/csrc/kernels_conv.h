@@ -67,6 +67,13 @@ struct ConvArgs {
   // idles while the whole chip reads residuals and writes outputs, and HBM idles during the K-loops
   // (profiles/r02_split_ablation_microbench.txt: the phases add up instead of overlapping).
   int stagger_units, stagger_slots, stagger_mode;
+  // Chunked accumulation of the fp32 MFMA kernels' small tiles (coarse U-Net levels): kchunk_stages > 0 -> the reduction over the
+  // input channels is the sum, in chunk order, of per-chunk partial sums (each an MFMA chain from zero over kchunk_stages K-stages).
+  // With gridDim.z == 1 a workgroup runs all chunks itself; with gridDim.z == number of chunks each workgroup computes ONE chunk
+  // and stores the raw partial sums to `partial` [chunk][B][Cout][H][W], summed in the same order (and run through the
+  // epilogue) by conv_splitk_reduce_kernel: bit-identical results, but the chunks run on different CUs (small batches).
+  int kchunk_stages;
+  float* partial;
   // measurement (ABL bit 6 instantiation): per workgroup {hw_id | xcc_id << 32, t_start, t_loop, t_epilogue, t_end} (shader clock)
   unsigned long long* trace;
 };
@@ -532,17 +539,97 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
   };
 
   const int nstages = Cin / KC;
-  load_stage(0);
-  __syncthreads();  // s_sc / s_sh visible
   const bool abl_stage = p.ablate & 4, abl_bar = p.ablate & 8;
-  for (int ci = 0; ci < nstages; ++ci) {
-    if (!abl_stage || ci == 0) store_stage(ci * KC);
-    if (!abl_bar) __syncthreads();
-    if (ci + 1 < nstages && !abl_stage) load_stage((ci + 1) * KC);   // in flight during the MFMAs
-    compute();
-    if (!abl_bar) __syncthreads();
+  if constexpr (FC * FP <= 2) {
+    // small tiles (coarse levels): optional chunked accumulation / split-K, see ConvArgs::kchunk_stages
+    const int cs = p.kchunk_stages > 0 ? p.kchunk_stages : nstages;
+    const bool splitk = gridDim.z > 1;
+    const int ci0 = splitk ? (int)blockIdx.z * cs : 0;
+    const int ci1 = splitk ? (ci0 + cs < nstages ? ci0 + cs : nstages) : nstages;
+    f32x16 tot[FC][FP];
+    bool first = true;
+    load_stage(ci0 * KC);
+    __syncthreads();  // s_sc / s_sh visible
+    for (int ci = ci0; ci < ci1; ++ci) {
+      store_stage(ci * KC);
+      __syncthreads();
+      if (ci + 1 < ci1) load_stage((ci + 1) * KC);   // in flight during the MFMAs
+      compute();
+      __syncthreads();
+      if (p.kchunk_stages > 0 && !splitk && ((ci + 1) % cs == 0 || ci + 1 == ci1)) {   // end of a chunk: total += partial
+#pragma unroll
+        for (int i = 0; i < FC; ++i)
+#pragma unroll
+          for (int j = 0; j < FP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { tot[i][j][r] = first ? acc[i][j][r] : tot[i][j][r] + acc[i][j][r]; acc[i][j][r] = 0.f; }
+        first = false;
+      }
+    }
+    if (p.kchunk_stages > 0 && !splitk) {
+#pragma unroll
+      for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FP; ++j) acc[i][j] = tot[i][j];
+    }
+    if (splitk) {                                      // raw partial sums of this chunk; the reduce kernel runs the epilogue
+      ConvArgs q = p;
+      q.out = p.partial + (size_t)blockIdx.z * p.B * p.Cout * H * W;
+      q.bias = nullptr; q.bias2 = nullptr; q.res = nullptr; q.acc_scale = nullptr; q.out_scale = 1.f; q.stats_out = nullptr; q.amax_out = nullptr;
+      conv_epilogue<T, FC, FP, WC>(q, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
+      return;
+    }
+  } else {
+    load_stage(0);
+    __syncthreads();  // s_sc / s_sh visible
+    for (int ci = 0; ci < nstages; ++ci) {
+      if (!abl_stage || ci == 0) store_stage(ci * KC);
+      if (!abl_bar) __syncthreads();
+      if (ci + 1 < nstages && !abl_stage) load_stage((ci + 1) * KC);   // in flight during the MFMAs
+      compute();
+      if (!abl_bar) __syncthreads();
+    }
   }
 
+  conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
+}
+
+// Second half of a split-K convolution (ConvArgs::kchunk_stages): sums the chunks' partial sums in chunk order into the
+// accumulator layout of the producing tile shape and runs the ordinary epilogue (bias, time embedding, residual, scale,
+// GroupNorm partials, range bound).  grid = (tiles, output-channel blocks) of the tile shape <KS, WC, FC, FP>.
+template <int KS, int WC, int FC, int FP>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int nchunks) {
+  using T = ConvTile<KS, WC, FC, FP, 1>;
+  constexpr int ROWS = T::ROWS, CO_T = T::CO_T;
+  const int tid = threadIdx.x;
+  const int H = p.H, W = p.W;
+  const int tiles_x = (W + 31) >> 5;
+  const int tiles_y = (H + ROWS - 1) / ROWS;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int co_blk = blockIdx.y;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+  const int wc = wave % WC, wp = wave / WC;
+  const size_t slab = (size_t)p.B * p.Cout * H * W;
+  const int x = tx * 32 + l31;
+  f32x16 acc[FC][FP];
+#pragma unroll
+  for (int i = 0; i < FC; ++i)
+#pragma unroll
+    for (int j = 0; j < FP; ++j) {
+      const int y = ty * ROWS + wp * FP + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+        const bool ok = co < p.Cout && y < H && x < W;
+        const size_t o = ok ? ((size_t)(b * p.Cout + co) * H + y) * W + x : 0;
+        float t = 0.f;
+        for (int z = 0; z < nchunks; ++z) { const float v = p.partial[(size_t)z * slab + o]; t = z == 0 ? v : t + v; }
+        acc[i][j][r] = ok ? t : 0.f;
+      }
+    }
   conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
 }
 

@@ -89,6 +89,9 @@ __device__ __forceinline__ float drt_xadd(float a, float b) {
 }
 __device__ __forceinline__ float drt_add_xor2(float a) { return drt_dpp_add<0x4E>(a); }
 
+// execution barrier among the lanes of one wave around wave-private LDS traffic: the hardware runs a wave in lock step and
+// executes its LDS operations in order, so this only pins the compiler's ordering (the emulator synchronises its fibers)
+__device__ __forceinline__ void drt_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #define DRT_PIN_HERE(x) asm volatile("" : "+v"(x))
 #define DRT_CODE_MARKER(n) asm volatile("; code marker %0" ::"n"(n))
 #define DRT_LAUNCH(kern, grid, block, stream, ...) \

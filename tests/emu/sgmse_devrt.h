@@ -108,6 +108,7 @@ static inline float atomicAdd(float* p, float v) {
 }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
+static inline void drt_wave_sync() { (void)emu::shfl_idx(0.f, 0); }
 #define DRT_PIN_HERE(x) ((void)0)
 #define DRT_CODE_MARKER(n) ((void)0)
 #define DRT_LAUNCH(kern, grid, block, stream, ...) \

@@ -170,7 +170,9 @@ def check_forward_golden(dev, name, batch=None):
     else:
         out = net(x.to(dev), t.to(dev))
     assert out.shape == ref.shape and out.dtype == torch.complex64
-    assert rel_l2(out.cpu(), ref) < NET_TOL, name
+    err = rel_l2(out.cpu(), ref)
+    print(f"{name} on {dev}: rel_l2 vs the reference's output = {err:.3e}")
+    assert err < NET_TOL, (name, err)
 
 
 def check_tile_independence(dev, name, batch=None):
