@@ -105,6 +105,12 @@ inline int split_blk() {
 template <class S, int SHAPE>
 inline void launch_conv3x3_split_t(const ConvArgs& a, dim3 grid, drt::stream_t st) {
   const bool act = a.in_scale && a.in_act;
+  if constexpr (SHAPE != 1 && S::SCALED) {
+    if (a.sc_w) {                                  // folded residual shortcut (fp16x2, SiLU producer, full-block shapes)
+      DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1, 0, 0, 1>), grid, dim3(256), st, a);
+      return;
+    }
+  }
   if constexpr (SHAPE == 0) {
     if (split_blk() == 1) {
       if (act) DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1, 0, 1>), grid, dim3(256), st, a);

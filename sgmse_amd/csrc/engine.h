@@ -1061,8 +1061,20 @@ class Engine {
     for (int k = 0; k < 2; ++k) if (tmp[k]) arena_.release(tmp[k]);
   }
 
+  // residual shortcut folded into a 3x3 split launch (ConvArgs::sc_*): the 1x1 layer and its (raw) input
+  struct Shortcut { const ConvW* w; const Tensor* a; const Tensor* b; };
+  // would conv() run this 3x3 layer (GroupNorm producer in front) on the fp16x2 split kernel at this image size?  (the rule below)
+  bool runs_on_h2_split3(const ConvW& w, int C, int H, int W) const {
+    return w.packed && w.packed_split && w.split_mode == 2 && w.ks == 3 && w.cout > 32 && conv_split_eligible(3, C, 0, w.cout) &&
+           (long)((H + 7) / 8) * ((W + 31) / 32) >= split_min_tiles_;
+  }
+  bool shortcut_foldable(const ConvW& c2, const Tensor& a, const Tensor* b) const {
+    return fold_shortcut_ && c2.packed_split && c2.split_mode == 2 && c2.ks == 1 && conv_split_eligible(1, a.C, b ? b->C : 0, c2.cout) &&
+           a.amax && (!b || b->amax);
+  }
+
   Tensor conv(const ConvW& w, const Tensor& a, const Tensor* b, const Xform& xf, const float* bias, const float* bias2,
-              const float* res, float out_scale, const FwdCtl& ctl, bool emit_stats = false) {
+              const float* res, float out_scale, const FwdCtl& ctl, bool emit_stats = false, const Shortcut* sc = nullptr) {
     const int Cin = a.C + (b ? b->C : 0);
     SG_REQUIRE(Cin == w.cin, "conv: channel mismatch");
     Tensor o = new_tensor(w.cout, a.H, a.W);
@@ -1133,7 +1145,16 @@ class Engine {
     ca.in_scale = xf.scale; ca.in_shift = xf.shift; ca.in_act = xf.act;
     ca.res = res; ca.out_scale = out_scale; ca.out = o.p; ca.Cout = w.cout; ca.B = B_; ca.H = a.H; ca.W = a.W;
     tock();
-    const double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
+    double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
+    if (sc) {
+      SG_REQUIRE(use_split && w.ks == 3 && w.split_mode == 2 && w.cout > 32 && xf.scale && xf.act && !res, "conv: shortcut fold on an ineligible launch");
+      const int Cs = sc->a->C + (sc->b ? sc->b->C : 0);
+      SG_REQUIRE(Cs == sc->w->cin && sc->w->cout == w.cout && sc->a->H == a.H && sc->a->W == a.W, "conv: shortcut shape mismatch");
+      ca.sc_src1 = sc->a->p; ca.sc_src2 = sc->b ? sc->b->p : nullptr; ca.sc_C1 = sc->a->C; ca.sc_C2 = sc->b ? sc->b->C : 0;
+      ca.sc_w = sc->w->packed_split; ca.sc_scale = sc->w->split_scale; ca.sc_bias = sc->w->bias;
+      ca.sc_amax1 = sc->a->amax; ca.sc_amax2 = sc->b ? sc->b->amax : nullptr;
+      fl += 2.0 * B_ * (double)w.cout * Cs * a.H * a.W;
+    }
     if (use_split) {
       ca.w = w.packed_split; ca.acc_scale = w.split_scale;
       if (w.ks == 1 && w.split_mode == 2) { ca.amax1 = a.amax; ca.amax2 = b ? b->amax : nullptr; }
@@ -1149,7 +1170,8 @@ class Engine {
       }
       launch_conv_split(ca, w.ks, w.split_mode, stream_, rows4);
       if (prof_ && prof_dump_)
-        snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "");
+        snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "",
+                 sc ? " +shortcut" : "");
       tick(w.ks == 3 ? (w.cout >= 128 ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else if (use_mfma) {
       ConvPlan pl{co_t, rows_, true};
@@ -1230,10 +1252,17 @@ class Engine {
     Tensor out;
     const float inv_sqrt2 = 0.70710678118654752440f;
     if (r.has_c2) {
-      Tensor sh_t = have_xs ? conv(r.c2, xs, nullptr, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl)
-                            : conv(r.c2, a, b, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl);
-      out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, sh_t.p, inv_sqrt2, ctl, true);
-      drop(sh_t);
+      const Tensor& sa = have_xs ? xs : a;
+      const Tensor* sb = have_xs ? nullptr : b;
+      if (runs_on_h2_split3(r.c1, h.C, h.H, h.W) && shortcut_foldable(r.c2, sa, sb)) {
+        // (Conv_1(h) + Conv_2(x)) / sqrt 2 as one accumulation: the shortcut's K-stages run inside the 3x3 launch
+        const Shortcut scin{&r.c2, &sa, sb};
+        out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, nullptr, inv_sqrt2, ctl, true, &scin);
+      } else {
+        Tensor sh_t = conv(r.c2, sa, sb, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl);
+        out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, sh_t.p, inv_sqrt2, ctl, true);
+        drop(sh_t);
+      }
     } else {
       SG_REQUIRE(b == nullptr, "identity shortcut with concat input");
       out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, a.p, inv_sqrt2, ctl, true);
@@ -1447,7 +1476,8 @@ class Engine {
     split_stagger_ = e ? atol(e) : SGMSE_SPLIT_STAGGER_DEFAULT;
     e = getenv("SGMSE_SPLIT_STAGGER_MODE");
     split_stagger_mode_ = e ? atoi(e) : 0;
-    coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);   // chunked accumulation (+ split-K) of the coarse levels' fp32 layers
+    coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);
+    fold_shortcut_ = flag("SGMSE_FOLD_SHORTCUT", true);     // 1x1 residual shortcuts as K-stages of the following 3x3 split launch   // chunked accumulation (+ split-K) of the coarse levels' fp32 layers
   }
   // per-forward range-bound slots ([B][kAmaxSpread] floats each), handed out in program order; counted by the dry run
   float* amax_pool_ = nullptr; size_t amax_pool_floats_ = 0; int amax_slots_ = 0, amax_next_ = 0;
@@ -1459,7 +1489,7 @@ class Engine {
   }
   long tile_min_blocks_ = 512, split_min_tiles_ = 8, split_stagger_ = SGMSE_SPLIT_STAGGER_DEFAULT;
   int split_stagger_mode_ = 0;
-  bool coarse_chunked_ = true;
+  bool coarse_chunked_ = true, fold_shortcut_ = true;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};

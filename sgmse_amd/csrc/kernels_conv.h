@@ -67,6 +67,14 @@ struct ConvArgs {
   // idles while the whole chip reads residuals and writes outputs, and HBM idles during the K-loops
   // (profiles/r02_split_ablation_microbench.txt: the phases add up instead of overlapping).
   int stagger_units, stagger_slots, stagger_mode;
+  // Folded residual shortcut of the split 3x3 kernel (ResnetBlockBigGANpp with a Conv_2, layerspp.py:266-274): out =
+  // (Conv_1(act(GN(h))) + Conv_2(x)) / sqrt 2 is ONE accumulation -- the 1x1 shortcut runs as extra K-stages (centre tap only)
+  // over the raw block input x in front of the 3x3 stages, instead of a separate launch that writes a tensor the 3x3 kernel
+  // reads back as its residual.  sc_src1 | sc_src2: x (virtual concat, sc_C1 + sc_C2 channels, same H x W); sc_w: its weights
+  // in the split kernels' fragment order (one tap); sc_scale: device scalar undoing the weights' power-of-two scale; sc_bias:
+  // Conv_2's bias; sc_amax1 / 2: range bounds of x, from which the input's power-of-two scale is derived per utterance.
+  const float* sc_src1; const float* sc_src2; int sc_C1, sc_C2;
+  const float* sc_w; const float* sc_scale; const float* sc_bias; const float* sc_amax1; const float* sc_amax2;
   // Chunked accumulation of the fp32 MFMA kernels' small tiles (coarse U-Net levels): kchunk_stages > 0 -> the reduction over the
   // input channels is the sum, in chunk order, of per-chunk partial sums (each an MFMA chain from zero over kchunk_stages K-stages).
   // With gridDim.z == 1 a workgroup runs all chunks itself; with gridDim.z == number of chunks each workgroup computes ONE chunk

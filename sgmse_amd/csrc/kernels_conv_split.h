@@ -190,7 +190,10 @@ inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<
 // BLK: register blocking of a wave inside the 128-channel block: 0 = 1 channel fragment x all pixel fragments (B operand
 // read by all four waves, A operand private), 1 = 2 channel fragments x half of the pixel fragments (half the LDS operand
 // reads; each A fragment loaded by two waves; the two channel fragments' MFMAs alternate, so no MFMA waits on its predecessor).
-template <class S, int SHAPE = 0, int ACT = 1, int ABL = 0, int BLK = 0>
+// SC = 1: with the folded 1x1 residual shortcut (ConvArgs::sc_*): its K-stages run first on accumulators that start from
+// zero; the accumulators are then rescaled by the (exact, power-of-two) ratio of the two operand scalings, receive the
+// bias terms, and the 3x3 stages continue on top.
+template <class S, int SHAPE = 0, int ACT = 1, int ABL = 0, int BLK = 0, int SC = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   constexpr bool THIN = SHAPE == 1;
   constexpr int ROWS = SHAPE == 2 ? 4 : 8;
@@ -351,7 +354,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
 #pragma unroll
   for (int i = 0; i < FCW; ++i) {
     float init[16];
-    conv_acc_init<T>(p, b, co_blk, wc * FCW + i, kg, 1.0f, init);
+    if constexpr (SC) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) init[r] = 0.f;
+    } else {
+      conv_acc_init<T>(p, b, co_blk, wc * FCW + i, kg, 1.0f, init);
+    }
 #pragma unroll
     for (int j = 0; j < FPW; ++j)
 #pragma unroll
@@ -408,6 +416,80 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     }
   };
 
+  if constexpr (SC) {
+    // ---- folded 1x1 shortcut: K-stages of 16 channels of the raw block input, centre tap only -------------------------------
+    static_assert(S::SCALED && !THIN, "the folded shortcut exists for the fp16x2 full-block shapes");
+    float m = amax_read(p.sc_amax1, b);
+    if (p.sc_amax2) m = fmaxf(m, amax_read(p.sc_amax2, b));
+    const float xs = h2_weight_scale(m);                 // max |x| 2^s in [2^13, 2^14) for this utterance
+    const int nsts = (p.sc_C1 + p.sc_C2) / C::KC;
+    auto load_sc = [&](int i, int c0) {
+      const bool first = c0 < p.sc_C1;
+      const float* base = first ? p.sc_src1 + ((size_t)b * p.sc_C1 + c0) * HW : p.sc_src2 + ((size_t)b * p.sc_C2 + (c0 - p.sc_C1)) * HW;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        rin[i][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (size_t)e * HW) + it_boff[i]);
+    };
+    auto store_sc = [&](int i, u32x4* sbuf) {
+      u32x4 v[NS];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t d[NS];
+        S::split2(fminf(fmaxf(rin[i][2 * q] * xs, -65504.f), 65504.f), fminf(fmaxf(rin[i][2 * q + 1] * xs, -65504.f), 65504.f), d);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s][q] = d[s];
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) sbuf[it_loff[i] + s] = v[s];
+    };
+    const u32x4* wsc = reinterpret_cast<const u32x4*>(p.sc_w) + (size_t)co_blk * nsts * NS * 4 * 64;
+    auto load_asc = [&](int st, u32x4 (&a)[FCW][NS]) {
+      const u32x4* q = wsc + (size_t)st * NS * 4 * 64;
+#pragma unroll
+      for (int i = 0; i < FCW; ++i)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          a[i][s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s * 4 * 64 + i * 64) + a_boff);
+    };
+#pragma unroll
+    for (int i = 0; i < C::NIT; ++i) load_sc(i, 0);
+    __syncthreads();          // the zero padding visible
+#pragma unroll
+    for (int i = 0; i < C::NIT; ++i) store_sc(i, s_in0);
+    __syncthreads();
+    u32x4 asc[FCW][NS];
+#pragma unroll 1
+    for (int st = 0; st < nsts; ++st) {
+      const u32x4* cur = (st & 1) ? s_in1 : s_in0;
+      u32x4* nxt = (st & 1) ? s_in0 : s_in1;
+      load_asc(st, asc);
+      if (st + 1 < nsts) {
+#pragma unroll
+        for (int i = 0; i < C::NIT; ++i) load_sc(i, (st + 1) * C::KC);
+      }
+      compute_tap(cur, 4, asc, -1, 0, nxt);
+      if (st + 1 < nsts) {
+#pragma unroll
+        for (int i = 0; i < C::NIT; ++i) store_sc(i, nxt);
+      }
+      __syncthreads();
+    }
+    // accumulator: from the shortcut's operand scaling (weights 2^k1, input xs) to the 3x3 stages' (acc_scale), plus the biases
+    const float as3 = *p.acc_scale;
+    const float rho = (*p.sc_scale / xs) / as3;
+#pragma unroll
+    for (int i = 0; i < FCW; ++i) {
+      float init[16];
+      conv_acc_init<T>(p, b, co_blk, wc * FCW + i, kg, 1.0f, init);
+      const int co_l = co_blk * T::CO_T + (wc * FCW + i) * 32 + 4 * kg;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) init[r] += p.sc_bias ? p.sc_bias[co_l + (r & 3) + 8 * (r >> 2)] / as3 : 0.f;
+#pragma unroll
+      for (int j = 0; j < FPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * rho + init[r];
+    }
+  }
   // prologue: stage 0 -> s_in0
 #pragma unroll
   for (int i = 0; i < C::NIT; ++i) load_item(i, 0);
