@@ -423,24 +423,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     if (p.sc_amax2) m = fmaxf(m, amax_read(p.sc_amax2, b));
     const float xs = h2_weight_scale(m);                 // max |x| 2^s in [2^13, 2^14) for this utterance
     const int nsts = (p.sc_C1 + p.sc_C2) / C::KC;
-    auto load_sc = [&](int i, int c0) {
+    // raw inputs two stages ahead in two register sets: a stage has only 24 MFMAs per wave to cover its loads
+    float rsc[C::NIT][8];
+    auto load_sc = [&](int c0, float (&dst)[C::NIT][8]) {
       const bool first = c0 < p.sc_C1;
       const float* base = first ? p.sc_src1 + ((size_t)b * p.sc_C1 + c0) * HW : p.sc_src2 + ((size_t)b * p.sc_C2 + (c0 - p.sc_C1)) * HW;
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        rin[i][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (size_t)e * HW) + it_boff[i]);
+      for (int i = 0; i < C::NIT; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          dst[i][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (size_t)e * HW) + it_boff[i]);
     };
-    auto store_sc = [&](int i, u32x4* sbuf) {
-      u32x4 v[NS];
+    auto store_sc = [&](const float (&src)[C::NIT][8], u32x4* sbuf) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        uint32_t d[NS];
-        S::split2(fminf(fmaxf(rin[i][2 * q] * xs, -65504.f), 65504.f), fminf(fmaxf(rin[i][2 * q + 1] * xs, -65504.f), 65504.f), d);
+      for (int i = 0; i < C::NIT; ++i) {
+        u32x4 v[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) v[s][q] = d[s];
+        for (int q = 0; q < 4; ++q) {
+          uint32_t d[NS];
+          S::split2(fminf(fmaxf(src[i][2 * q] * xs, -65504.f), 65504.f), fminf(fmaxf(src[i][2 * q + 1] * xs, -65504.f), 65504.f), d);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) v[s][q] = d[s];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sbuf[it_loff[i] + s] = v[s];
       }
-#pragma unroll
-      for (int s = 0; s < NS; ++s) sbuf[it_loff[i] + s] = v[s];
     };
     const u32x4* wsc = reinterpret_cast<const u32x4*>(p.sc_w) + (size_t)co_blk * nsts * NS * 4 * 64;
     auto load_asc = [&](int st, u32x4 (&a)[FCW][NS]) {
@@ -451,28 +458,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
         for (int s = 0; s < NS; ++s)
           a[i][s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s * 4 * 64 + i * 64) + a_boff);
     };
-#pragma unroll
-    for (int i = 0; i < C::NIT; ++i) load_sc(i, 0);
+    load_sc(0, rin);
+    load_sc((nsts > 1 ? 1 : 0) * C::KC, rsc);
     __syncthreads();          // the zero padding visible
-#pragma unroll
-    for (int i = 0; i < C::NIT; ++i) store_sc(i, s_in0);
+    store_sc(rin, s_in0);
     __syncthreads();
     u32x4 asc[FCW][NS];
+    // stage st: MFMAs from buffer st & 1, stage st + 1 (already in registers) through the producer into the other buffer, stage
+    // st + 2 loaded into the register set that just became free.  Two stages per iteration: the register sets alternate.
 #pragma unroll 1
-    for (int st = 0; st < nsts; ++st) {
-      const u32x4* cur = (st & 1) ? s_in1 : s_in0;
-      u32x4* nxt = (st & 1) ? s_in0 : s_in1;
+    for (int st = 0; st < nsts; st += 2) {
       load_asc(st, asc);
-      if (st + 1 < nsts) {
-#pragma unroll
-        for (int i = 0; i < C::NIT; ++i) load_sc(i, (st + 1) * C::KC);
-      }
-      compute_tap(cur, 4, asc, -1, 0, nxt);
-      if (st + 1 < nsts) {
-#pragma unroll
-        for (int i = 0; i < C::NIT; ++i) store_sc(i, nxt);
-      }
+      if (st + 2 < nsts) load_sc((st + 2) * C::KC, rin);
+      compute_tap(s_in0, 4, asc, -1, 0, s_in1);
+      if (st + 1 < nsts) store_sc(rsc, s_in1);
       __syncthreads();
+      if (st + 1 < nsts) {
+        load_asc(st + 1, asc);
+        if (st + 3 < nsts) load_sc((st + 3) * C::KC, rsc);
+        compute_tap(s_in1, 4, asc, -1, 0, s_in0);
+        if (st + 2 < nsts) store_sc(rin, s_in0);
+        __syncthreads();
+      }
     }
     // accumulator: from the shortcut's operand scaling (weights 2^k1, input xs) to the 3x3 stages' (acc_scale), plus the biases
     const float as3 = *p.acc_scale;
