@@ -52,4 +52,14 @@ if os.environ.get("CALIB") == "1":
         ops.group_norm(x, w, w)
     torch.cuda.synchronize()
     res["_calibration"] = {"gn_chan_stats_kernel_read_bytes_per_launch": x.numel() * 4}
+    # the HBM-bound kernel classes of the network under the same counters: FIR resamplers with the fused producer and both
+    # outputs (as the residual blocks call them), algorithmic bytes = input once + outputs once
+    sc, sh = torch.randn(8, 128, device="cuda"), torch.randn(8, 128, device="cuda")
+    for up in (False, True):
+        xin = x if not up else x[:, :, :128, :256].contiguous()
+        for _ in range(3):
+            ops.fir_resample(xin, up, in_scale=sc, in_shift=sh, in_act=True, return_raw=True)
+        torch.cuda.synchronize()
+        n_out = xin.numel() * (4 if up else 1) // (1 if up else 4)
+        res["_calibration"]["fir_%s2_tiled_kernel_algorithmic_bytes_per_launch" % ("up" if up else "down")] = 4 * (xin.numel() + 2 * n_out)
 json.dump(res, open(os.path.join(out_dir, os.environ.get("OUT", "conv_microbench.json")), "w"), indent=1)

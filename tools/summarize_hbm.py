@@ -13,12 +13,17 @@ import json
 import sys
 
 
+DUR = collections.defaultdict(list)      # kernel -> launch durations (ns) under the counter passes
+
+
 def collect(d, counter):
     acc = collections.defaultdict(list)
     for f in glob.glob(d + "/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+                k = r["Kernel_Name"].split("(")[0]
+                acc[k].append(float(r["Counter_Value"]))
+                DUR[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return acc
 
 
@@ -36,11 +41,25 @@ if known and gn:
 out = {"_read_correction": {"factor": corr, "source": note}}
 for k in sorted(set(fetch) | set(write), key=lambda n: -sum(fetch.get(n, [0]))):
     f, w = fetch.get(k, []), write.get(k, [])
-    c = corr if ("conv_mfma_kernel" in k or "gn_chan_stats_kernel" in k) else 1.0
+    c = corr if any(n in k for n in ("conv_mfma_kernel", "gn_chan_stats_kernel", "fir_down2_tiled", "fir_up2_tiled", "gn_finalize")) else 1.0
     rd = sum(f) / max(len(f), 1) * 1024.0 * c
     wr = sum(w) / max(len(w), 1) * 1024.0
     out[k] = {"launches": len(f), "fetch_bytes_per_launch": rd, "fetch_correction": c, "write_bytes_per_launch": wr,
               "hbm_bytes_per_launch": rd + wr}
+    if DUR.get(k):
+        us = sorted(DUR[k])[len(DUR[k]) // 2] / 1e3
+        out[k]["median_duration_us_under_pmc"] = us
+        out[k]["hbm_gb_per_s"] = (rd + wr) / (us * 1e-6) / 1e9 if us > 0 else None
+for name, val in calib.items():
+    if name.endswith("_algorithmic_bytes_per_launch"):
+        kern = name[:-len("_algorithmic_bytes_per_launch")]
+        for k in out:
+            if kern in k and isinstance(out[k], dict):
+                out[k]["algorithmic_bytes_per_launch"] = val
+                if out[k].get("median_duration_us_under_pmc"):
+                    out[k]["algorithmic_gb_per_s"] = val / (out[k]["median_duration_us_under_pmc"] * 1e-6) / 1e9
+if False:
+    pass
 alg = [v["algorithmic_bytes_per_launch"] for k, v in micro.items() if not k.startswith("_")]
 if alg:
     out["_algorithmic_bytes_per_launch_of_the_benchmarked_conv"] = sum(alg) / len(alg)
