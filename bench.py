@@ -63,6 +63,49 @@ def parse():
     return ap.parse_args()
 
 
+class PowerSampler:
+    """Socket power and shader clock from rocm-smi, sampled in a background thread during the timed region (rank 0, N = 1).  The
+    dominant kernel runs AT the socket power cap (profiles/r02_power_probe.txt): its clock -- and with it the achievable share
+    of the nominal MFMA peak -- is set by energy per tile, which is what this evidence is for."""
+
+    def __init__(self, period=0.5):
+        import threading
+        self.period, self.rows = period, []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
+                card = next(iter(json.loads(r.stdout).values()))
+                p = next((float(v) for k, v in card.items() if "Power" in k and "(W)" in k), None)
+                c = next((float(v.strip("()").lower().replace("mhz", "")) for k, v in card.items() if k.lower().startswith("sclk clock speed")), None)
+                if p is not None:
+                    self.rows.append((p, c))
+            except Exception:       # noqa: BLE001 -- rocm-smi missing or busy: no power evidence, the benchmark goes on
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join(timeout=10)
+
+    def summary(self):
+        if not self.rows:
+            return None
+        ps = [r[0] for r in self.rows]
+        cs = [r[1] for r in self.rows if r[1]]
+        return {"samples": len(ps), "socket_power_w_mean": sum(ps) / len(ps), "socket_power_w_max": max(ps),
+                "sclk_mhz_mean": (sum(cs) / len(cs)) if cs else None,
+                "note": "rocm-smi during the timed region; the MI355X socket power cap is 1400 W and the maximum shader clock 2400 MHz"}
+
+
 def spawn_ranks(a):
     """`bench.py --gpus N` started by hand (no torchrun around it): start the N ranks ourselves, one per GPU, exactly as the
     driver does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...), and hand their exit code back."""
@@ -225,11 +268,16 @@ def main():
     for i in range(a.warmup):
         _, nfe = step(i)
     fence()
+    power = PowerSampler() if (rank == 0 and world == 1 and not emu) else None
+    if power:
+        power.__enter__()
     t0 = time.perf_counter()
     for i in range(a.steps):
         x_hat, nfe = step(a.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    if power:
+        power.__exit__()
     per_rank = [elapsed]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -266,6 +314,8 @@ def main():
             "path_tflops": a.batch * a.steps * nfe * flop_eval / elapsed / 1e12,
             "path_frac_of_fp32_peak": a.batch * a.steps * nfe * flop_eval / elapsed / 1e12 / FP32_PEAK_TFLOPS,
         }
+        if power and power.summary():
+            out["power"] = power.summary()
         out["graph_captures_rank0"] = model.dnn.engine(dev).graph_captures()   # 1: the seed changes per step, the captured step does not
         if world > 1:
             out["weight_broadcast_ms"] = bcast_ms
