@@ -64,14 +64,16 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnArgs p) {
 
   for (int kt = wave; kt < nkt; kt += 4) {
     const int r0 = kt * 32;
-    const bool kok = (r0 + l31) < S;
-    // row (channel 2 i + kh), column (key r0 + l31): one VGPR byte offset per lane + a uniform offset per row pair
-    const unsigned lane_boff = (unsigned)(kh * S + r0 + l31) * 4u;
+    // row (channel 2 i + kh), column (key r0 + l31): one VGPR byte offset per lane + a uniform offset per row pair.  Keys past
+    // the end are CLAMPED to the last one instead of predicated (a predicated load is a branch and a full vmcnt wait each):
+    // their scores are set to -inf below, so their k values never matter and their (finite) v values meet a weight of exactly 0
+    const int kcol = (r0 + l31) < S ? r0 + l31 : S - 1;
+    const unsigned lane_boff = (unsigned)(kh * S + kcol) * 4u;
     // this wave's V tile: row (channel) 2 i + kh of chunk h, column (key) l31; in flight during the QK^T loop
     float vreg[FH * 16];
     auto load_v = [&](int h) {
 #pragma unroll
-      for (int i = 0; i < FH * 16; ++i) vreg[i] = kok ? drt_buf_load(vbuf, lane_boff, (unsigned)(h * FH * 32 + 2 * i) * rowb) : 0.f;
+      for (int i = 0; i < FH * 16; ++i) vreg[i] = drt_buf_load(vbuf, lane_boff, (unsigned)(h * FH * 32 + 2 * i) * rowb);
     };
     load_v(0);
 
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnArgs p) {
     float ka0[16], ka1[16];
     auto load_k = [&](int ch, float (&dst)[16]) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) dst[i] = kok ? drt_buf_load(kbuf, lane_boff, (unsigned)(ch * 32 + 2 * i) * rowb) : 0.f;
+      for (int i = 0; i < 16; ++i) dst[i] = drt_buf_load(kbuf, lane_boff, (unsigned)(ch * 32 + 2 * i) * rowb);
     };
     auto qk = [&](int ch, const float (&src)[16]) {
 #pragma unroll

@@ -666,12 +666,11 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs p) {
     for (int t = 0; t < TAPS; ++t) {
       const int gy = y + t / KS - HALO, gx = x + t % KS - HALO;
       const bool ok = inb && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      float u = 0.f;
-      if (ok) {
-        u = plane[gy * W + gx];
-        if (xform) { u = u * sc + sh; if (p.in_act) u = silu_f(u); }
-      }
-      v[t] = u;
+      // unconditional load from a clamped address, masked afterwards: a predicated load is a branch plus a full vmcnt wait
+      const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+      float u = plane[gyc * W + gxc];
+      if (xform) { u = u * sc + sh; if (p.in_act) u = silu_f(u); }
+      v[t] = ok ? u : 0.f;
     }
 #pragma unroll
     for (int g = 0; g < CG; ++g) {
