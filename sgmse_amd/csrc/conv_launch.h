@@ -111,13 +111,15 @@ inline void launch_conv3x3_split_t(const ConvArgs& a, dim3 grid, drt::stream_t s
       return;
     }
   }
+#ifdef SGMSE_ABLATION_FULL
   if constexpr (SHAPE == 0) {
-    if (split_blk() == 1) {
+    if (split_blk() == 1) {            // 2 x 4 register blocking: measured equal to 1 x 8 (profiles/r02: gpu_r02_blk.sh), not built by default
       if (act) DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1, 0, 1>), grid, dim3(256), st, a);
       else DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 0, 0, 1>), grid, dim3(256), st, a);
       return;
     }
   }
+#endif
   if (act) DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1>), grid, dim3(256), st, a);
   else DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 0>), grid, dim3(256), st, a);
 }
@@ -140,8 +142,13 @@ inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t
   const dim3 grid(tiles, a.Cout / 128, 1);
   if (abl && mode == 2) {
 #define SGMSE_ABL_CASE(V) if (abl == V) { DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 0, 1, V>), grid, dim3(256), st, a); return; }
-    SGMSE_ABL_CASE(3) SGMSE_ABL_CASE(4) SGMSE_ABL_CASE(8) SGMSE_ABL_CASE(24) SGMSE_ABL_CASE(56) SGMSE_ABL_CASE(59)
-    SGMSE_ABL_CASE(1) SGMSE_ABL_CASE(2) SGMSE_ABL_CASE(64) SGMSE_ABL_CASE(67) SGMSE_ABL_CASE(72) SGMSE_ABL_CASE(128) SGMSE_ABL_CASE(256) SGMSE_ABL_CASE(512)
+    // the variants tools/power_probe.py and the phase trace need are always built; the full series behind
+    // profiles/r02_split_*.txt with `make ABLATION=1` (each instantiation of this kernel costs ~6 s of build time)
+    SGMSE_ABL_CASE(8) SGMSE_ABL_CASE(59) SGMSE_ABL_CASE(64)
+#ifdef SGMSE_ABLATION_FULL
+    SGMSE_ABL_CASE(3) SGMSE_ABL_CASE(4) SGMSE_ABL_CASE(24) SGMSE_ABL_CASE(56)
+    SGMSE_ABL_CASE(1) SGMSE_ABL_CASE(2) SGMSE_ABL_CASE(67) SGMSE_ABL_CASE(72) SGMSE_ABL_CASE(128) SGMSE_ABL_CASE(256) SGMSE_ABL_CASE(512)
+#endif
 #undef SGMSE_ABL_CASE
   }
   if (mode == 2) launch_conv3x3_split_t<SplitH2, 0>(a, grid, st); else launch_conv3x3_split_t<SplitB3, 0>(a, grid, st);

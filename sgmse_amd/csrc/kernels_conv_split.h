@@ -29,8 +29,17 @@
 //     lanes a ds_read_b128 services per LDS cycle hit distinct banks.  Two stages are double buffered; the fused
 //     producer (GroupNorm affine + SiLU) and the split run once per staged element;
 //   * A operand (weights): packed offline in fragment order [co block][stage][tap][split][wave][lane][8 x 16 bit], so a
-//     fragment is one coalesced 16-byte global load per lane (L2-resident), prefetched one tap ahead.  No LDS.
+//     fragment is one coalesced 16-byte global load per lane (L2-resident), in a ring of three register sets two taps ahead.
+//     No LDS.
 //   * K order: stage (16 channels) -> tap -> split products, small terms first.  Epilogue shared with the fp32 kernels.
+//
+// What bounds it (round 2, profiles/r02_power_probe.txt, r02_split_ablation_microbench.txt, r02_split_trace_*.txt): the f16
+// matrix pipe on random data drives the socket to its 1400 W power cap, the clock settles at ~1.5 GHz, and the kernel's time is
+// its dynamic ENERGY divided by (cap - static power): MFMAs 60 %, the epilogue's HBM traffic 17 %, input staging 12 %, weight
+// fragments from L2 8 %.  Stalls are nearly free, bytes and MFMAs are not: structures that only re-order the instruction stream
+// (finer MFMA / VALU interleave, a deeper fragment ring, a 2 x 4 register blocking with half the LDS reads, a start-up stagger
+// of the workgroups, 4-row tiles at three workgroups per CU) measured within +-2 %; halving the producer's VALU work and an
+// epilogue with a fifth of the instructions gained 4 %.
 #pragma once
 #include "kernels_conv.h"
 
