@@ -1099,19 +1099,36 @@ class Engine {
     }
     // fp32-accurate bf16x3 kernel for the wide levels.  Decided per layer and per IMAGE (never by the batch size), because
     // its results differ from the fp32-MFMA kernels in the last bits and an utterance must not depend on its batch.
-    const bool use_split = use_mfma && w.packed_split &&
+    const long tiles8 = (long)((a.H + 7) / 8) * ((a.W + 31) / 32);
+    // Levels with 2-7 tiles per image (16 x 32): the fp16x2 split kernel too, in its 4-row shape with CHUNKED accumulation, so
+    // that a small batch can spread the chunks over workgroups (split-K, bit-identical) instead of running 16-32 serial stages
+    // on 8 workgroups; full 3x3 blocks behind a GroupNorm producer only (no folded shortcut on these)
+    const bool coarse_split = coarse_split_ && use_mfma && w.packed_split && w.split_mode == 2 && w.ks == 3 && w.cout > 32 && !sc &&
+                              conv_split_eligible(3, a.C, b ? b->C : 0, w.cout) && tiles8 >= 2 && tiles8 < split_min_tiles_ &&
+                              (xf.scale != nullptr || xf.bounded);
+    const bool use_split = coarse_split || (use_mfma && w.packed_split &&
                         (conv_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout) || conv_thin_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout)) &&
-                        (long)((a.H + 7) / 8) * ((a.W + 31) / 32) >= split_min_tiles_ &&
+                        tiles8 >= split_min_tiles_ &&
                         // fp16x2: 3x3 layers presume the O(1) output of a GroupNorm producer (fixed scale); 1x1 layers read the
                         // raw residual stream and scale by the producers' range bounds, which must then be known
                         (w.split_mode != 2 || (w.ks == 3 ? (xf.scale != nullptr || xf.bounded)
-                                                         : (xf.scale == nullptr && a.amax && (!b || b->amax))));
+                                                         : (xf.scale == nullptr && a.amax && (!b || b->amax)))));
     // Coarse levels (at most 512 pixels per image) on the fp32 kernels: 32-channel tiles with CHUNKED accumulation (decided per
     // layer and image, never by the batch: it fixes the summation order), and -- when even those tiles leave most CUs idle
     // (small batches) -- the chunks spread over workgroups (split-K, bit-identical): a K loop of 32-64 serial stages was the
     // latency of these launches (60-120 us each at batch 1, profiles/r02_prof_dump_b1_per_launch.txt)
     int kchunk = 0, ksplit = 1;
     float* partial = nullptr;
+    if (coarse_split) {
+      const int nstages = Cin / 16;
+      kchunk = std::max(2, (nstages + 7) / 8);
+      const int nchunks = (nstages + kchunk - 1) / kchunk;
+      const long nblk = (long)B_ * ((a.H + 3) / 4) * ((a.W + 31) / 32) * (w.cout / 128);
+      if (nchunks > 1 && nblk * coarse_splitk_div_ <= tile_min_blocks_) {
+        ksplit = nchunks;
+        partial = arena_.alloc((size_t)nchunks * B_ * w.cout * a.H * a.W);
+      }
+    }
     if (use_mfma && !use_split && coarse_chunked_ && (long)a.H * a.W <= 512 && (w.co_t == 32 || w.packed32)) {
       co_t = 32;
       const long nblk8 = (long)B_ * ((a.H + 7) / 8) * ((a.W + 31) / 32) * ((w.cout + 31) / 32);
@@ -1160,7 +1177,8 @@ class Engine {
       if (w.ks == 1 && w.split_mode == 2) { ca.amax1 = a.amax; ca.amax2 = b ? b->amax : nullptr; }
       // 4-row workgroups when 8-row ones would leave CUs idle (bit-identical results, so this may follow the batch size)
       const long nblk8 = (long)B_ * ((a.H + 7) / 8) * ((a.W + 31) / 32) * ((w.cout + 127) / 128);
-      const bool rows4 = nblk8 < tile_min_blocks_;
+      const bool rows4 = coarse_split || nblk8 < tile_min_blocks_;
+      if (coarse_split) { ca.kchunk_stages = kchunk; ca.partial = partial; }
       // start-up stagger (ConvArgs::stagger_units): only for launches of several residency rounds, where the one-time fill
       // is small against what the de-phased rounds gain
       const long slots = rows4 ? 768 : 512;
@@ -1168,7 +1186,8 @@ class Engine {
         ca.stagger_units = (int)std::max(1L, (long)(Cin / 16) * split_stagger_ / 16 / 8128);
         ca.stagger_slots = (int)slots; ca.stagger_mode = split_stagger_mode_;
       }
-      launch_conv_split(ca, w.ks, w.split_mode, stream_, rows4);
+      launch_conv_split(ca, w.ks, w.split_mode, stream_, rows4, 0, ksplit);
+      if (coarse_split && partial) arena_.release(partial);
       if (prof_ && prof_dump_)
         snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "",
                  sc ? " +shortcut" : "");
@@ -1477,7 +1496,10 @@ class Engine {
     e = getenv("SGMSE_SPLIT_STAGGER_MODE");
     split_stagger_mode_ = e ? atoi(e) : 0;
     coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);
-    fold_shortcut_ = flag("SGMSE_FOLD_SHORTCUT", true);     // 1x1 residual shortcuts as K-stages of the following 3x3 split launch   // chunked accumulation (+ split-K) of the coarse levels' fp32 layers
+    fold_shortcut_ = flag("SGMSE_FOLD_SHORTCUT", true);
+    coarse_split_ = flag("SGMSE_COARSE_SPLIT", true);        // 16 x 32 level on the chunked 4-row fp16x2 split kernel
+    e = getenv("SGMSE_COARSE_SPLITK_DIV");                  // ... whose chunks go to separate workgroups below tile_min_blocks / this
+    coarse_splitk_div_ = e ? atol(e) : 1000000L;            // (measured: split-K of this kernel only adds prologues; effectively off)     // 1x1 residual shortcuts as K-stages of the following 3x3 split launch   // chunked accumulation (+ split-K) of the coarse levels' fp32 layers
   }
   // per-forward range-bound slots ([B][kAmaxSpread] floats each), handed out in program order; counted by the dry run
   float* amax_pool_ = nullptr; size_t amax_pool_floats_ = 0; int amax_slots_ = 0, amax_next_ = 0;
@@ -1489,7 +1511,8 @@ class Engine {
   }
   long tile_min_blocks_ = 512, split_min_tiles_ = 8, split_stagger_ = SGMSE_SPLIT_STAGGER_DEFAULT;
   int split_stagger_mode_ = 0;
-  bool coarse_chunked_ = true, fold_shortcut_ = true;
+  bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true;
+  long coarse_splitk_div_ = 1000000;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};

@@ -202,8 +202,13 @@ inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<
 // SC = 1: with the folded 1x1 residual shortcut (ConvArgs::sc_*): its K-stages run first on accumulators that start from
 // zero; the accumulators are then rescaled by the (exact, power-of-two) ratio of the two operand scalings, receive the
 // bias terms, and the 3x3 stages continue on top.
-template <class S, int SHAPE = 0, int ACT = 1, int ABL = 0, int BLK = 0, int SC = 0>
+// CHK = 1 (4-row shape, levels with 2-7 tiles per image): chunked accumulation / split-K as in the fp32 kernels
+// (ConvArgs::kchunk_stages, stages of 16 channels): the K reduction is the sum, in chunk order, of per-chunk partial sums; one
+// workgroup runs all chunks (gridDim.z == 1) or one chunk each (gridDim.z == chunks, raw partial sums to ConvArgs::partial,
+// summed and finished by conv_splitk_reduce_kernel<3, 4, 1, 4>) -- bit-identical.  The bias terms are added by the epilogue.
+template <class S, int SHAPE = 0, int ACT = 1, int ABL = 0, int BLK = 0, int SC = 0, int CHK = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
+  static_assert(!CHK || (SHAPE == 2 && !SC && !BLK), "chunked accumulation exists for the plain 4-row shape");
   constexpr bool THIN = SHAPE == 1;
   constexpr int ROWS = SHAPE == 2 ? 4 : 8;
   using C = ConvSplitGeom<ROWS>;
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
 #pragma unroll
   for (int i = 0; i < FCW; ++i) {
     float init[16];
-    if constexpr (SC) {
+    if constexpr (SC || CHK) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) init[r] = 0.f;
     } else {
@@ -506,12 +511,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * rho + init[r];
     }
   }
-  // prologue: stage 0 -> s_in0
+  // this workgroup's K-stages: all of them, or (split-K) one chunk
+  int st0 = 0, st1 = nst;
+  if constexpr (CHK) {
+    if (gridDim.z > 1) { st0 = (int)blockIdx.z * p.kchunk_stages; st1 = st0 + p.kchunk_stages < nst ? st0 + p.kchunk_stages : nst; }
+  }
+  // prologue: first stage -> s_in0
 #pragma unroll
-  for (int i = 0; i < C::NIT; ++i) load_item(i, 0);
+  for (int i = 0; i < C::NIT; ++i) load_item(i, st0 * C::KC);
   __syncthreads();          // s_co and the zero padding visible
 #pragma unroll
-  for (int i = 0; i < C::NIT; ++i) store_item(i, 0, s_in0);
+  for (int i = 0; i < C::NIT; ++i) store_item(i, st0 * C::KC, s_in0);
   __syncthreads();
 
   if constexpr (ABL & 64) { if (trace) trace[2] = drt_clock(); }
@@ -521,21 +531,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   // latency on every tap (profiles/r02_split_ablation_microbench.txt: staging, fragment loads and the epilogue's memory
   // traffic each ADDED their time to the K loop).  9 taps % 3 == 0: the ring index of a tap is the same in every stage.
   unsigned long long tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // ABL 64: time per tap position and at the stage barrier (wave 0)
-  u32x4 ar[3][FCW][NS];
-  load_a(0, 0, ar[0]);
-  load_a(0, 1, ar[1]);
+  // (a ring holding a whole stage -- 9 sets, 8 taps ahead -- for the 4-row shape, whose taps have half the MFMAs to cover a
+  // load, measured no gain at batch 1 and costs the third workgroup per CU: profiles/r02 gpu_r02_coarse.sh)
+  constexpr int AR = 3, AD = AR - 1;
+  u32x4 ar[AR][FCW][NS];
+#pragma unroll
+  for (int t = 0; t < AD; ++t) load_a(st0, t, ar[t]);
+  f32x16 tot[CHK ? FCW : 1][CHK ? FPW : 1];      // chunked accumulation: running total of the finished chunks
+  bool first_chunk = true;
   if constexpr (ABL & 16) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) { bq[0][s] = s_in0[b_lane + s]; bq[1][s] = s_in0[b_lane + C::TCOLS * PX_V + s]; }
   }
-  if constexpr (ABL & 32) load_a(0, 2, ar[2]);
+  if constexpr (ABL & 32) load_a(0, 2, ar[2]);     // (ABL 32: ring of 3, all loaded once)
 #pragma unroll 1
-  for (int st = 0; st < nst; ++st) {
+  for (int st = st0; st < st1; ++st) {
     // the stage after this one, clamped: the last stage re-stages itself into the buffer nobody reads again, which
     // keeps the loop body free of branches
-    const int stn = st + 1 < nst ? st + 1 : st;
-    const u32x4* cur = (st & 1) ? s_in1 : s_in0;
-    u32x4* nxt = (st & 1) ? s_in0 : s_in1;
+    const int stn = st + 1 < st1 ? st + 1 : st;
+    const u32x4* cur = ((st - st0) & 1) ? s_in1 : s_in0;
+    u32x4* nxt = ((st - st0) & 1) ? s_in0 : s_in1;
     // Per tap: the A fragments of the tap after next first (vmcnt retires in order: they must be OLDER than the raw HBM
     // loads of the next stage issued behind them, or every tap would wait for HBM), then one item of raw loads (taps 0-2);
     // producer + split + LDS write of those items three or more taps later (taps 4, 6, 8).
@@ -543,14 +558,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     for (int tap = 0; tap < 9; ++tap) {
       unsigned long long tc0 = 0;
       if constexpr (ABL & 64) tc0 = drt_clock();
-      const int ntap = (tap + 2) % 9;
-      const int nstg = tap + 2 < 9 ? st : stn;
-      if constexpr (!(ABL & 32)) load_a(nstg, ntap, ar[(tap + 2) % 3]);
+      const int ntap = (tap + AD) % 9;
+      const int nstg = tap + AD < 9 ? st : stn;
+      if constexpr (!(ABL & 32)) load_a(nstg, ntap, ar[(tap + AD) % AR]);
       if constexpr (!(ABL & 8)) { if (tap < C::NIT) load_item(tap, stn * C::KC); }
       __builtin_amdgcn_sched_barrier(0);
       int item = (tap >= 4 && (tap & 1) == 0 && (tap - 4) / 2 < C::NIT) ? (tap - 4) / 2 : -1;   // taps 4, 6, 8: items 0, 1, 2
       if constexpr (ABL & 8) item = -1;
-      compute_tap(cur, tap, ar[tap % 3], item, stn * C::KC, nxt);
+      compute_tap(cur, tap, ar[tap % AR], item, stn * C::KC, nxt);
       if constexpr (ABL & 64) { __builtin_amdgcn_sched_barrier(0); tsum[tap] += drt_clock() - tc0; }
     }
     if constexpr (ABL & 64) {
@@ -559,6 +574,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       tsum[9] += drt_clock() - tb;
     } else {
       __syncthreads();
+    }
+    if constexpr (CHK) {
+      if (gridDim.z == 1 && ((st + 1) % p.kchunk_stages == 0 || st + 1 == st1)) {      // a chunk is complete: total += chunk
+#pragma unroll
+        for (int i = 0; i < FCW; ++i)
+#pragma unroll
+          for (int j = 0; j < FPW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { tot[i][j][r] = first_chunk ? acc[i][j][r] : tot[i][j][r] + acc[i][j][r]; acc[i][j][r] = 0.f; }
+        first_chunk = false;
+      }
+    }
+  }
+  if constexpr (CHK) {
+    if (gridDim.z == 1) {
+#pragma unroll
+      for (int i = 0; i < FCW; ++i)
+#pragma unroll
+        for (int j = 0; j < FPW; ++j) acc[i][j] = tot[i][j];
+    } else {                                        // raw partial sums of this chunk; the reduce kernel runs the epilogue
+      ConvArgs q = p;
+      q.out = p.partial + (size_t)blockIdx.z * p.B * p.Cout * H * W;
+      q.bias = nullptr; q.bias2 = nullptr; q.res = nullptr; q.acc_scale = nullptr; q.out_scale = 1.f; q.stats_out = nullptr; q.amax_out = nullptr;
+      conv_epilogue<T, FCW, FPW, WCW, 0, true>(q, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg);
+      return;
     }
   }
   if constexpr (ABL & 64) {
@@ -569,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   }
 
   if constexpr (ABL & 64) { if (trace) trace[3] = drt_clock(); }
-  conv_epilogue<T, FCW, FPW, WCW, ABL & (3 | 128 | 256), true>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg);
+  conv_epilogue<T, FCW, FPW, WCW, ABL & (3 | 128 | 256), !CHK>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg);
   if constexpr (ABL & 64) { if (trace) trace[4] = drt_clock(); }
 }
 

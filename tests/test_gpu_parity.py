@@ -355,6 +355,12 @@ def test_conv_tile_shape_never_changes_a_bit(hip):
     P.check_tile_independence(hip, "fwd_nf32")
 
 
+def test_split_k_of_the_coarse_levels_never_changes_a_bit(hip):
+    """Full-width network: the chunked layers of the coarse levels (fp32 kernels and the 4-row fp16x2 kernel of the 16 x 32 level)
+    with every chunk on its own workgroup vs all chunks in one workgroup -- chosen by the workgroup count, i.e. the batch size."""
+    P.check_tile_independence(hip, "fwd_nf128")
+
+
 def test_enhancement_script_directory_to_directory(hip, tmp_path, monkeypatch):
     P.check_enhancement_script(hip, tmp_path, monkeypatch)
 
