@@ -1100,11 +1100,12 @@ class Engine {
     // fp32-accurate bf16x3 kernel for the wide levels.  Decided per layer and per IMAGE (never by the batch size), because
     // its results differ from the fp32-MFMA kernels in the last bits and an utterance must not depend on its batch.
     const long tiles8 = (long)((a.H + 7) / 8) * ((a.W + 31) / 32);
-    // Levels with 2-7 tiles per image (16 x 32): the fp16x2 split kernel too, in its 4-row shape with CHUNKED accumulation, so
-    // that a small batch can spread the chunks over workgroups (split-K, bit-identical) instead of running 16-32 serial stages
-    // on 8 workgroups; full 3x3 blocks behind a GroupNorm producer only (no folded shortcut on these)
+    // Levels with 2..chunk_max_tiles_ tiles per image (16 x 32, 32 x 64): the fp16x2 split kernel in its 4-row shape with CHUNKED
+    // accumulation, so that a small batch can spread the chunks over workgroups (split-K, bit-identical) instead of running 16-32
+    // serial stages on 8-32 workgroups; full 3x3 blocks behind a GroupNorm producer only (not the launches with a folded
+    // shortcut).  Decided per layer and image size, never by the batch: chunking fixes the summation order.
     const bool coarse_split = coarse_split_ && use_mfma && w.packed_split && w.split_mode == 2 && w.ks == 3 && w.cout > 32 && !sc &&
-                              conv_split_eligible(3, a.C, b ? b->C : 0, w.cout) && tiles8 >= 2 && tiles8 < split_min_tiles_ &&
+                              conv_split_eligible(3, a.C, b ? b->C : 0, w.cout) && tiles8 >= 2 && tiles8 <= chunk_max_tiles_ &&
                               (xf.scale != nullptr || xf.bounded);
     const bool use_split = coarse_split || (use_mfma && w.packed_split &&
                         (conv_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout) || conv_thin_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout)) &&
@@ -1497,9 +1498,11 @@ class Engine {
     split_stagger_mode_ = e ? atoi(e) : 0;
     coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);
     fold_shortcut_ = flag("SGMSE_FOLD_SHORTCUT", true);
-    coarse_split_ = flag("SGMSE_COARSE_SPLIT", true);        // 16 x 32 level on the chunked 4-row fp16x2 split kernel
+    coarse_split_ = flag("SGMSE_COARSE_SPLIT", true);        // chunked 4-row fp16x2 split kernel for levels of few tiles per image
+    e = getenv("SGMSE_CHUNK_MAX_TILES");                    // ... up to this many 8x32 tiles per image (2: the 16 x 32 level only)
+    chunk_max_tiles_ = e ? atol(e) : 8L;                    //     (8: the 16 x 32 and 32 x 64 levels of a 256 x 512 input)
     e = getenv("SGMSE_COARSE_SPLITK_DIV");                  // ... whose chunks go to separate workgroups below tile_min_blocks / this
-    coarse_splitk_div_ = e ? atol(e) : 1000000L;            // (measured: split-K of this kernel only adds prologues; effectively off)     // 1x1 residual shortcuts as K-stages of the following 3x3 split launch   // chunked accumulation (+ split-K) of the coarse levels' fp32 layers
+    coarse_splitk_div_ = e ? atol(e) : 4L;                  //     (batch 1: 0.503 -> 0.457 s per utterance, profiles/r02_chunk_splitk.txt)
   }
   // per-forward range-bound slots ([B][kAmaxSpread] floats each), handed out in program order; counted by the dry run
   float* amax_pool_ = nullptr; size_t amax_pool_floats_ = 0; int amax_slots_ = 0, amax_next_ = 0;
@@ -1512,7 +1515,7 @@ class Engine {
   long tile_min_blocks_ = 512, split_min_tiles_ = 8, split_stagger_ = SGMSE_SPLIT_STAGGER_DEFAULT;
   int split_stagger_mode_ = 0;
   bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true;
-  long coarse_splitk_div_ = 1000000;
+  long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};

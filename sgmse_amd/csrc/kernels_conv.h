@@ -623,6 +623,32 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
   const size_t slab = (size_t)p.B * p.Cout * H * W;
   const int x = tx * 32 + l31;
   f32x16 acc[FC][FP];
+  // chunk loop OUTSIDE: the FC*FP*16 loads of one chunk are independent and in flight together; an element still sums its
+  // chunks in chunk order (what makes split-K bit-identical to the chunked single-workgroup run)
+  for (int z = 0; z < nchunks; ++z) {
+    const float* pz = p.partial + (size_t)z * slab;
+    f32x16 v[FC][FP];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+      for (int j = 0; j < FP; ++j) {
+        const int y = ty * ROWS + wp * FP + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+          const bool ok = co < p.Cout && y < H && x < W;
+          v[i][j][r] = pz[ok ? ((size_t)(b * p.Cout + co) * H + y) * W + x : 0];      // clamped, unpredicated
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);      // (left alone the compiler runs load - wait - add through ONE register, 16*FC*FP round trips)
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+      for (int j = 0; j < FP; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = z == 0 ? v[i][j][r] : acc[i][j][r] + v[i][j][r];
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int i = 0; i < FC; ++i)
 #pragma unroll
@@ -631,11 +657,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
-        const bool ok = co < p.Cout && y < H && x < W;
-        const size_t o = ok ? ((size_t)(b * p.Cout + co) * H + y) * W + x : 0;
-        float t = 0.f;
-        for (int z = 0; z < nchunks; ++z) { const float v = p.partial[(size_t)z * slab + o]; t = z == 0 ? v : t + v; }
-        acc[i][j][r] = ok ? t : 0.f;
+        if (!(co < p.Cout && y < H && x < W)) acc[i][j][r] = 0.f;
       }
     }
   conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
