@@ -159,7 +159,16 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs p) {
   p.dst[e] = v;
 }
 
-// deterministic pseudo-random fill in [-1, 1) (benchmark operands must not be zeros: DVFS, MI355X_MICROARCH.md)
+// OIHW weights with the input channels zero-padded from cin to cin_pad (entry convolution on the MFMA kernels)
+__global__ __launch_bounds__(256) void pad_cin_kernel(const float* src, float* dst, int cout, int cin, int cin_pad, int taps) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)cout * cin_pad * taps) return;
+  const int t = (int)(e % taps);
+  const int c = (int)((e / taps) % cin_pad);
+  const int co = (int)(e / ((size_t)taps * cin_pad));
+  dst[e] = c < cin ? src[((size_t)co * cin + c) * taps + t] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void zero_floats_kernel(float* p, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0.f;
@@ -812,8 +821,11 @@ class Engine {
   }
 
   ConvW make_conv(const std::string& wname, const std::string& bname, int ks, int cin, int cout) {
+    return make_conv(Wp(wname), bname.empty() ? nullptr : Wp(bname), ks, cin, cout);
+  }
+  ConvW make_conv(const float* oihw, const float* bias, int ks, int cin, int cout, int force_split_mode = -1) {
     ConvW c; c.ks = ks; c.cin = cin; c.cout = cout;
-    c.oihw = Wp(wname); c.bias = bname.empty() ? nullptr : Wp(bname);
+    c.oihw = oihw; c.bias = bias;
     ConvPlan pl = choose_conv_plan(ks, cin, cout, 8, 32);
     if (pl.mfma) {
       c.co_t = pl.co_t;
@@ -834,7 +846,7 @@ class Engine {
     // fp16x2: 3x3 layers scale their (GroupNorm-produced) input by a fixed 2^4, 1x1 layers (raw residual stream) by a
     // power of two derived at run time from the producers' range bounds -- the stored factor then only undoes the weights'
     if (split_mode_ && (conv_split_eligible(ks, cin, 0, cout) || conv_thin_split_eligible(ks, cin, 0, cout))) {
-      c.split_mode = split_mode_;
+      c.split_mode = force_split_mode > 0 ? force_split_mode : split_mode_;
       c.packed_split = pack_split(c.oihw, ks, cin, cout, c.split_mode, true, &c.split_scale, ks == 3 ? kH2XScale : 1.f);
     }
     return c;
@@ -920,6 +932,18 @@ class Engine {
         attn_[m.idx] = a;
       } else if (m.kind == Mod::CONV3) {
         conv_[m.idx] = make_conv(p + "weight", p + "bias", 3, m.cin, m.cout);
+        if (m.cin == 4 && entry_mfma_) {
+          // Entry convolution (4 -> nf on the full-resolution image, ncsnpp.py:286): as a direct VALU kernel it was bound by
+          // its scalar weight loads (1.6 ms at batch 32 for a 0.36 ms output write, plus a 0.4 ms statistics pass).  With the
+          // input channels zero-padded to one K-stage it runs on the MFMA kernels, GroupNorm partials fused: 16 channels on the
+          // range-free bf16x3 split kernel (the raw spectrogram has no bound the fp16x2 kernel could scale by), or 8 channels
+          // on the fp32 kernel when the split kernels are off (SGMSE_CONV_SPLIT=0)
+          const int cp = (split_mode_ && conv_split_eligible(3, 16, 0, m.cout)) ? 16 : 8;
+          float* w8 = static_cast<float*>(dev_alloc_w((size_t)m.cout * cp * 9 * 4));
+          DRT_LAUNCH(pad_cin_kernel, dim3((unsigned)(((size_t)m.cout * cp * 9 + 255) / 256)), dim3(256), stream_, Wp(p + "weight"), w8, m.cout, 4, cp, 9);
+          entry8_ = make_conv(w8, Wp(p + "bias"), 3, cp, m.cout, 1);
+          entry8_idx_ = m.idx;
+        }
       } else if (m.kind == Mod::COMBINE) {
         conv_[m.idx] = make_conv(p + "Conv_0.weight", p + "Conv_0.bias", 1, m.cin, m.cout);
       } else if (m.kind == Mod::GN) {
@@ -1330,13 +1354,19 @@ class Engine {
     const int FT = F * T;
 
     Tensor xr = new_tensor(4, F, T);
+    const bool entry8 = entry_mfma_ && entry8_.packed && layout_[mi].idx == entry8_idx_;
+    Tensor xr8{};
+    if (entry8) xr8 = new_tensor(entry8_.cin, F, T);   // the same four planes + planes of zeros: one K-stage of the MFMA kernel
     if (!dry_) { tock(); const WrapCoef wc{ctl.coef, ctl.coef_bstride, ctl.coef_sstride, ctl.step_ptr, ctl.sign};
-      DRT_LAUNCH(entry_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, x, xbs, y, ybs, xr.p, FT, wc); tick(TC_MISC, 32.0 * B * FT); }
+      DRT_LAUNCH(entry_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, x, xbs, y, ybs, xr.p, entry8 ? xr8.p : (float*)nullptr,
+                 entry8 ? entry8_.cin : 0, FT, wc);
+      tick(TC_MISC, (32.0 + (entry8 ? 4.0 * entry8_.cin : 0.0)) * B * FT); }
     std::vector<Tensor> hs;
     {
       const Mod& m = next();
-      const ConvW& w = conv_.at(m.idx);
-      hs.push_back(conv(w, xr, nullptr, Xform{}, w.bias, nullptr, nullptr, 1.f, ctl, true));
+      const ConvW& w = entry8 ? entry8_ : conv_.at(m.idx);
+      hs.push_back(conv(w, entry8 ? xr8 : xr, nullptr, Xform{}, w.bias, nullptr, nullptr, 1.f, ctl, true));
+      if (entry8) drop(xr8);
     }
     Tensor pyr_in = xr;   // input pyramid (ncsnpp.py:293-296); released at the end / when replaced
     bool pyr_in_is_xr = true;
@@ -1497,6 +1527,7 @@ class Engine {
     e = getenv("SGMSE_SPLIT_STAGGER_MODE");
     split_stagger_mode_ = e ? atoi(e) : 0;
     coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);
+    entry_mfma_ = flag("SGMSE_ENTRY_MFMA", true);           // entry convolution on the fp32 MFMA kernel (input channels padded to 8)
     fold_shortcut_ = flag("SGMSE_FOLD_SHORTCUT", true);
     coarse_split_ = flag("SGMSE_COARSE_SPLIT", true);        // chunked 4-row fp16x2 split kernel for levels of few tiles per image
     e = getenv("SGMSE_CHUNK_MAX_TILES");                    // ... up to this many 8x32 tiles per image (2: the 16 x 32 level only)
@@ -1514,7 +1545,8 @@ class Engine {
   }
   long tile_min_blocks_ = 512, split_min_tiles_ = 8, split_stagger_ = SGMSE_SPLIT_STAGGER_DEFAULT;
   int split_stagger_mode_ = 0;
-  bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true;
+  bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true, entry_mfma_ = true;
+  ConvW entry8_{}; int entry8_idx_ = -1;
   long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;

@@ -265,8 +265,9 @@ __device__ __forceinline__ void wrap_coef(const WrapCoef& w, int b, float* gamma
 }
 
 // Network entry (ncsnpp.py:262-263 / ncsnpp_v2.py:247): complex x_t, y -> real [B][4][F*T] = gamma*(x.re, x.im, y.re, y.im).
+// xr8 (optional): the same planes in a C8-channel tensor whose other channels are zero (input of the entry convolution on the MFMA kernels)
 __global__ __launch_bounds__(256) void entry_kernel(const float2* x, long long xbs, const float2* y, long long ybs,
-                                                    float* xr, int FT, WrapCoef w) {
+                                                    float* xr, float* xr8, int C8, int FT, WrapCoef w) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= FT) return;
   const int b = blockIdx.y;
@@ -274,7 +275,13 @@ __global__ __launch_bounds__(256) void entry_kernel(const float2* x, long long x
   wrap_coef(w, b, &g, &al, &be);
   const float2 xv = x[(size_t)b * xbs + i], yv = y[(size_t)b * ybs + i];
   float* o = xr + (size_t)b * 4 * FT + i;
-  o[0] = g * xv.x; o[FT] = g * xv.y; o[2 * (size_t)FT] = g * yv.x; o[3 * (size_t)FT] = g * yv.y;
+  const float v0 = g * xv.x, v1 = g * xv.y, v2 = g * yv.x, v3 = g * yv.y;
+  o[0] = v0; o[FT] = v1; o[2 * (size_t)FT] = v2; o[3 * (size_t)FT] = v3;
+  if (xr8) {
+    float* q = xr8 + (size_t)b * C8 * FT + i;
+    q[0] = v0; q[FT] = v1; q[2 * (size_t)FT] = v2; q[3 * (size_t)FT] = v3;
+    for (int k = 4; k < C8; ++k) q[(size_t)k * FT] = 0.f;
+  }
 }
 
 // Network exit (ncsnpp.py:402-419 / ncsnpp_48k.py:414-421 / ncsnpp_v2.py:388-394) fused with the score wrapper:

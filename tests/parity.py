@@ -3,6 +3,7 @@ sgmse_amd path on ``dev`` and compares it with the oracle (oracle/, CPU torch fp
 the reference itself (tests/golden/, oracle/make_golden.py)."""
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -549,3 +550,53 @@ def check_enhancement_script(dev, tmp_path, monkeypatch):
     assert seen == 3 and sorted(str(p.relative_to(tmp_path / "o3")) for p in (tmp_path / "o3").rglob("*.wav")) == sorted(lengths)
     for name in lengths:                                   # two ranks, other batches: the same samples
         assert np.array_equal(wavfile.read(str(tmp_path / "o1" / name))[1], wavfile.read(str(tmp_path / "o3" / name))[1])
+
+
+def check_reference_script_unmodified(dev, tmp_path, monkeypatch):
+    """The reference's own ``enhancement.py``, byte for byte as it lies in the reference tree, run on top of this package:
+    ``sgmse_amd/compat`` resolves its ``from sgmse...`` imports, ``sgmse_amd/compat/shims`` stands in for the audio packages this
+    image lacks (soundfile / torchaudio / librosa; appended to the path, so real installations win).  Its output for the first
+    file equals, bit for bit, what ``python -m sgmse_amd.enhancement`` writes from the same torch seed; the second file (8 kHz:
+    the resampling branch) is checked for rate, length and sanity."""
+    import runpy
+    from scipy.io import wavfile
+    from sgmse_amd import enhancement as E
+    from sgmse_amd.model import ScoreModel
+    from sgmse_amd.data_module import SpecsDataModule
+    ref = os.path.join(os.environ.get("SGMSE_REFERENCE_DIR", "/root/reference"), "enhancement.py")
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present on this machine")
+    hp = dict(backbone="ncsnpp", sde="ouve", nf=32, theta=1.5, sigma_min=0.05, sigma_max=0.5, N=30, t_eps=0.03,
+              data_module_cls=SpecsDataModule, n_fft=510, hop_length=128, spec_factor=0.15, spec_abs_exponent=0.5)
+    src = ScoreModel(**hp)
+    src.dnn.load_state_dict(synth.synth_params(NET_CASES["fwd_nf32"], seed=0))
+    ckpt = tmp_path / "m.ckpt"
+    torch.save({"state_dict": {"dnn." + k: v.clone() for k, v in src.dnn.state_dict().items()}, "hyper_parameters": hp}, ckpt)
+    noisy = tmp_path / "noisy"
+    (noisy / "sub").mkdir(parents=True)
+    rng = torch.Generator().manual_seed(5)
+    wavfile.write(str(noisy / "a.wav"), 16000, (0.1 * torch.randn(2000, generator=rng)).numpy())
+    wavfile.write(str(noisy / "sub" / "b.wav"), 8000, (0.1 * torch.randn(1500, generator=rng)).numpy())     # -> 3000 samples at 16 kHz
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(os.path.join(root, "sgmse_amd", "compat"))
+    sys.path.append(os.path.join(root, "sgmse_amd", "compat", "shims"))
+    args = ["--test_dir", str(noisy), "--ckpt", str(ckpt), "--device", str(dev), "--N", "2"]
+    before = set(sys.modules)
+    try:
+        monkeypatch.setattr(sys, "argv", [ref] + args + ["--enhanced_dir", str(tmp_path / "ref_out")])
+        torch.manual_seed(3)
+        with pytest.warns(UserWarning):          # checkpoint without EMA weights (model.py:106)
+            runpy.run_path(ref, run_name="__main__")
+    finally:
+        sys.path.remove(os.path.join(root, "sgmse_amd", "compat", "shims"))
+        for name in set(sys.modules) - before:          # the alias package and the stand-ins leave with the script
+            if name.split(".")[0] in ("sgmse", "soundfile", "torchaudio", "librosa"):
+                del sys.modules[name]
+    torch.manual_seed(3)
+    with pytest.warns(UserWarning):
+        assert E.main(args + ["--enhanced_dir", str(tmp_path / "own_out"), "--batch_size", "1"]) == 2
+    sr, a_ref = wavfile.read(str(tmp_path / "ref_out" / "a.wav"))
+    _, a_own = wavfile.read(str(tmp_path / "own_out" / "a.wav"))
+    assert sr == 16000 and a_ref.shape == (2000,) and np.array_equal(a_ref, a_own)
+    sr, b_ref = wavfile.read(str(tmp_path / "ref_out" / "sub" / "b.wav"))
+    assert sr == 16000 and b_ref.shape == (3000,) and np.isfinite(b_ref).all() and np.abs(b_ref).max() > 0

@@ -227,3 +227,7 @@ def test_adversarial_checkpoint_residual_stream_growth(emu):
 
 def test_enhancement_script_directory_to_directory(emu, tmp_path, monkeypatch):
     P.check_enhancement_script(emu, tmp_path, monkeypatch)
+
+
+def test_reference_enhancement_script_runs_unmodified(emu, tmp_path, monkeypatch):
+    P.check_reference_script_unmodified(emu, tmp_path, monkeypatch)

@@ -6,7 +6,7 @@ set +e
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-STEPS=${STEPS:-smoke,pytest,micro,pmc,hbm,bench,rocprof,workloads}
+STEPS=${STEPS:-smoke,pytest,micro,pmc,hbm,bench,rocprof,workloads,dumps}
 has() { [[ ",$STEPS," == *",$1,"* ]]; }
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
 if has smoke; then echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -2 | tee gpurun_out/smoke.log; fi
@@ -54,5 +54,12 @@ if has workloads; then
     tail -1 gpurun_out/other_workloads.txt | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$args ->', round(d['value'],3), d['unit'], 'ms_per_step', round(d['ms_per_step'],1), 'rtf', round(d['rtf'],4), 'roofline frac', round(d.get('roofline',{}).get('frac',0),4))"
+  done
+fi
+if has dumps; then
+  echo "== per-launch timings of one evaluation (batch 32 and batch 1)"
+  for b in 32 1; do
+    SGMSE_PROFILE_DUMP=1 timeout 600 python bench.py --batch $b --N 2 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/prof_dump_b${b}_r02_final.txt
+    grep -c sgmse-prof gpurun_out/prof_dump_b${b}_r02_final.txt
   done
 fi
