@@ -823,7 +823,7 @@ class Engine {
   ConvW make_conv(const std::string& wname, const std::string& bname, int ks, int cin, int cout) {
     return make_conv(Wp(wname), bname.empty() ? nullptr : Wp(bname), ks, cin, cout);
   }
-  ConvW make_conv(const float* oihw, const float* bias, int ks, int cin, int cout, int force_split_mode = -1) {
+  ConvW make_conv(const float* oihw, const float* bias, int ks, int cin, int cout) {
     ConvW c; c.ks = ks; c.cin = cin; c.cout = cout;
     c.oihw = oihw; c.bias = bias;
     ConvPlan pl = choose_conv_plan(ks, cin, cout, 8, 32);
@@ -846,7 +846,7 @@ class Engine {
     // fp16x2: 3x3 layers scale their (GroupNorm-produced) input by a fixed 2^4, 1x1 layers (raw residual stream) by a
     // power of two derived at run time from the producers' range bounds -- the stored factor then only undoes the weights'
     if (split_mode_ && (conv_split_eligible(ks, cin, 0, cout) || conv_thin_split_eligible(ks, cin, 0, cout))) {
-      c.split_mode = force_split_mode > 0 ? force_split_mode : split_mode_;
+      c.split_mode = split_mode_;
       c.packed_split = pack_split(c.oihw, ks, cin, cout, c.split_mode, true, &c.split_scale, ks == 3 ? kH2XScale : 1.f);
     }
     return c;
@@ -935,13 +935,12 @@ class Engine {
         if (m.cin == 4 && entry_mfma_) {
           // Entry convolution (4 -> nf on the full-resolution image, ncsnpp.py:286): as a direct VALU kernel it was bound by
           // its scalar weight loads (1.6 ms at batch 32 for a 0.36 ms output write, plus a 0.4 ms statistics pass).  With the
-          // input channels zero-padded to one K-stage it runs on the MFMA kernels, GroupNorm partials fused: 16 channels on the
-          // range-free bf16x3 split kernel (the raw spectrogram has no bound the fp16x2 kernel could scale by), or 8 channels
-          // on the fp32 kernel when the split kernels are off (SGMSE_CONV_SPLIT=0)
-          const int cp = (split_mode_ && conv_split_eligible(3, 16, 0, m.cout)) ? 16 : 8;
+          // input channels zero-padded to one 8-channel K-stage it runs on the fp32 MFMA kernel, GroupNorm partials fused
+          // (1.07 ms; 16 channels on the bf16x3 split kernel measured the same at batch 32 and twice the time at batch 1)
+          constexpr int cp = 8;
           float* w8 = static_cast<float*>(dev_alloc_w((size_t)m.cout * cp * 9 * 4));
           DRT_LAUNCH(pad_cin_kernel, dim3((unsigned)(((size_t)m.cout * cp * 9 + 255) / 256)), dim3(256), stream_, Wp(p + "weight"), w8, m.cout, 4, cp, 9);
-          entry8_ = make_conv(w8, Wp(p + "bias"), 3, cp, m.cout, 1);
+          entry8_ = make_conv(w8, Wp(p + "bias"), 3, cp, m.cout);
           entry8_idx_ = m.idx;
         }
       } else if (m.kind == Mod::COMBINE) {
