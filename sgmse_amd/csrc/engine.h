@@ -1128,7 +1128,8 @@ class Engine {
     // serial stages on 8-32 workgroups; full 3x3 blocks behind a GroupNorm producer only (not the launches with a folded
     // shortcut).  Decided per layer and image size, never by the batch: chunking fixes the summation order.
     const bool coarse_split = coarse_split_ && use_mfma && w.packed_split && w.split_mode == 2 && w.ks == 3 && w.cout > 32 && !sc &&
-                              conv_split_eligible(3, a.C, b ? b->C : 0, w.cout) && tiles8 >= 2 && tiles8 <= chunk_max_tiles_ &&
+                              conv_split_eligible(3, a.C, b ? b->C : 0, w.cout) && tiles8 >= chunk_min_tiles_ && tiles8 <= chunk_max_tiles_ &&
+                              a.W >= chunk_min_width_ &&
                               (xf.scale != nullptr || xf.bounded);
     const bool use_split = coarse_split || (use_mfma && w.packed_split &&
                         (conv_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout) || conv_thin_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout)) &&
@@ -1531,6 +1532,10 @@ class Engine {
     coarse_split_ = flag("SGMSE_COARSE_SPLIT", true);        // chunked 4-row fp16x2 split kernel for levels of few tiles per image
     e = getenv("SGMSE_CHUNK_MAX_TILES");                    // ... up to this many 8x32 tiles per image (2: the 16 x 32 level only)
     chunk_max_tiles_ = e ? atol(e) : 8L;                    //     (8: the 16 x 32 and 32 x 64 levels of a 256 x 512 input)
+    e = getenv("SGMSE_CHUNK_MIN_TILES");                    //     from this many tiles and images at least SGMSE_CHUNK_MIN_WIDTH wide: the 8 x 16 and
+    chunk_min_tiles_ = e ? atol(e) : 2L;                    //     4 x 8 levels (1 tile, half / three quarters of each 32-pixel fragment row masked)
+    e = getenv("SGMSE_CHUNK_MIN_WIDTH");                    //     measured +0.8 % / +1.4 % at batch 32 and -2 % / -5 % at batch 1: left on the fp32 kernels
+    chunk_min_width_ = e ? atoi(e) : 32;                    //     (profiles/r02_chunk_splitk.txt)
     e = getenv("SGMSE_COARSE_SPLITK_DIV");                  // ... whose chunks go to separate workgroups below tile_min_blocks / this
     coarse_splitk_div_ = e ? atol(e) : 4L;                  //     (batch 1: 0.503 -> 0.457 s per utterance, profiles/r02_chunk_splitk.txt)
   }
@@ -1546,7 +1551,8 @@ class Engine {
   int split_stagger_mode_ = 0;
   bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true, entry_mfma_ = true;
   ConvW entry8_{}; int entry8_idx_ = -1;
-  long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8;
+  long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8, chunk_min_tiles_ = 2;
+  int chunk_min_width_ = 32;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};
