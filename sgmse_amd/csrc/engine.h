@@ -774,6 +774,7 @@ class Engine {
   void* dev_alloc_w(size_t bytes) {
     void* p = nullptr;
     SG_CHECK(drt::malloc_dev(&p, bytes ? bytes : 256));
+    if (poison_) SG_CHECK(drt::memset_dev(p, 0xFF, bytes ? bytes : 256, stream_));
     wowned_.push_back(p);
     return p;
   }
@@ -783,13 +784,22 @@ class Engine {
     for (void* p : wowned_) drt::free_dev(p);
     wowned_.clear();
   }
+  // SGMSE_POISON=1 (tests): every allocation, and the activation arena before every forward, is filled with 0xFF bytes (a NaN
+  // in every float), so that a kernel reading memory nobody wrote shows up as a NaN in the result instead of depending on
+  // what the allocation happened to hold
   void* dev_alloc(size_t bytes) {
     void* p = nullptr;
     SG_CHECK(drt::malloc_dev(&p, bytes ? bytes : 256));
+    if (poison_) SG_CHECK(drt::memset_dev(p, 0xFF, bytes ? bytes : 256, stream_));
     owned_.push_back(p);
     return p;
   }
-  void* dev_alloc_tmp(size_t bytes) { void* p = nullptr; SG_CHECK(drt::malloc_dev(&p, bytes ? bytes : 256)); return p; }
+  void* dev_alloc_tmp(size_t bytes) {
+    void* p = nullptr;
+    SG_CHECK(drt::malloc_dev(&p, bytes ? bytes : 256));
+    if (poison_) SG_CHECK(drt::memset_dev(p, 0xFF, bytes ? bytes : 256, stream_));
+    return p;
+  }
   void free_tmp(void* p) { drt::free_dev(p); }
   void dev_free_owned(void* p) {
     for (size_t i = 0; i < owned_.size(); ++i) if (owned_[i] == p) { owned_.erase(owned_.begin() + i); break; }
@@ -1343,6 +1353,7 @@ class Engine {
                    const FwdCtl& ctl) {
     B_ = B;
     amax_next_ = 0;
+    if (!dry_ && poison_ && arena_base_) SG_CHECK(drt::memset_dev(arena_base_, 0xFF, arena_cap_, stream_));
     if (!dry_ && amax_pool_) {
       const int n = amax_slots_ * B * kAmaxSpread;
       DRT_LAUNCH(zero_floats_kernel, dim3((n + 255) / 256), dim3(256), stream_, amax_pool_, n);
@@ -1527,6 +1538,7 @@ class Engine {
     e = getenv("SGMSE_SPLIT_STAGGER_MODE");
     split_stagger_mode_ = e ? atoi(e) : 0;
     coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);
+    poison_ = flag("SGMSE_POISON", false);
     entry_mfma_ = flag("SGMSE_ENTRY_MFMA", true);           // entry convolution on the fp32 MFMA kernel (input channels padded to 8)
     fold_shortcut_ = flag("SGMSE_FOLD_SHORTCUT", true);
     coarse_split_ = flag("SGMSE_COARSE_SPLIT", true);        // chunked 4-row fp16x2 split kernel for levels of few tiles per image
@@ -1551,6 +1563,7 @@ class Engine {
   int split_stagger_mode_ = 0;
   bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true, entry_mfma_ = true;
   ConvW entry8_{}; int entry8_idx_ = -1;
+  bool poison_ = false;
   long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8, chunk_min_tiles_ = 2;
   int chunk_min_width_ = 32;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;

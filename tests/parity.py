@@ -600,3 +600,32 @@ def check_reference_script_unmodified(dev, tmp_path, monkeypatch):
     assert sr == 16000 and a_ref.shape == (2000,) and np.array_equal(a_ref, a_own)
     sr, b_ref = wavfile.read(str(tmp_path / "ref_out" / "sub" / "b.wav"))
     assert sr == 16000 and b_ref.shape == (3000,) and np.isfinite(b_ref).all() and np.abs(b_ref).max() > 0
+
+
+def check_poison_independence(dev, name="fwd_nf128", every_layer_split=False):
+    """SGMSE_POISON=1 fills every device allocation, and the activation arena before every forward, with NaN bit patterns
+    (0xFF bytes): a kernel that reads memory nobody wrote -- a halo outside the image, a statistics slot of a masked row, a
+    split-K partial of a masked element -- turns that into a NaN.  The forward must give the same bits either way."""
+    cfg = NET_CASES[name]
+    z = load(name)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    keys = {"SGMSE_POISON": "0"}
+    if every_layer_split:
+        keys["SGMSE_SPLIT_MIN_TILES"] = "1"
+    old = {k: os.environ.get(k) for k in keys}
+    outs = []
+    try:
+        for poison in ("0", "1"):
+            os.environ.update(keys)
+            os.environ["SGMSE_POISON"] = poison
+            net, _ = make_backbone(cfg, dev)
+            outs.append(net(x.to(dev), t.to(dev)).cpu())
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert torch.isfinite(torch.view_as_real(outs[1])).all()
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[1], torch.from_numpy(z["out"])) < NET_TOL

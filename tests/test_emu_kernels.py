@@ -231,3 +231,7 @@ def test_enhancement_script_directory_to_directory(emu, tmp_path, monkeypatch):
 
 def test_reference_enhancement_script_runs_unmodified(emu, tmp_path, monkeypatch):
     P.check_reference_script_unmodified(emu, tmp_path, monkeypatch)
+
+
+def test_results_do_not_depend_on_what_device_memory_held(emu):
+    P.check_poison_independence(emu, "fwd_nf32")

@@ -361,6 +361,16 @@ def test_split_k_of_the_coarse_levels_never_changes_a_bit(hip):
     P.check_tile_independence(hip, "fwd_nf128")
 
 
+@pytest.mark.parametrize("every_layer_split", [False, True])
+def test_results_do_not_depend_on_what_device_memory_held(hip, every_layer_split):
+    P.check_poison_independence(hip, "fwd_nf128", every_layer_split)
+
+
+def test_sampler_does_not_depend_on_what_device_memory_held(hip, monkeypatch):
+    monkeypatch.setenv("SGMSE_POISON", "1")
+    P.check_sampler_golden(hip, "pc_N4")
+
+
 def test_enhancement_script_directory_to_directory(hip, tmp_path, monkeypatch):
     P.check_enhancement_script(hip, tmp_path, monkeypatch)
 
