@@ -1385,6 +1385,10 @@ class Engine {
       for (int rb = 0; rb < c.num_res_blocks; ++rb) {
         const Mod& m = next();
         Tensor h = res_block(m, hs.back(), nullptr, ctl);
+        // the reference's forward places attention by the ACTUAL height (ncsnpp.py:308) while its module list was built from the
+        // configured image_size (ncsnpp.py:189-193): an input of another height runs off the list there (TypeError); say why
+        SG_REQUIRE(cfg_has_attn(c, h.H) == cfg_has_attn(c, c.image_size >> l),
+                   "input height does not match the image_size the network was built for (attention placement, ncsnpp.py:308)");
         if (cfg_has_attn(c, h.H)) {
           const Mod& ma = next();
           Tensor h2 = attn_block(ma, h, ctl);
@@ -1427,6 +1431,8 @@ class Engine {
         drop(h); drop(skip);
         h = o;
       }
+      SG_REQUIRE(cfg_has_attn(c, h.H) == cfg_has_attn(c, c.image_size >> l),
+                 "input height does not match the image_size the network was built for (attention placement, ncsnpp.py:354)");
       if (cfg_has_attn(c, h.H)) {
         const Mod& ma = next();
         Tensor h2 = attn_block(ma, h, ctl);

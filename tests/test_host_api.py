@@ -184,6 +184,13 @@ def test_error_codes_and_messages(emu):
         ops.istft(torch.zeros(1, 256, 4, dtype=torch.complex64), 510, 128, torch.hann_window(510), length=10000)
     with pytest.raises(NotImplementedError):
         ops.spec_transform(torch.zeros(4, dtype=torch.complex64), "mel", 1.0, 1.0, False)
+    # an input whose height is not the image_size the module list was built for: the reference's forward places attention by
+    # the actual height (ncsnpp.py:308), runs off its module list and dies with a TypeError; here the error says why
+    import parity as P
+    from oracle import ncsnpp_oracle as NO
+    net, _ = P.make_backbone(NO.NetCfg.for_variant("ncsnpp", nf=32), "cpu")
+    with pytest.raises(RuntimeError, match="image_size"):
+        net(torch.zeros(1, 2, 64, 64, dtype=torch.complex64), torch.ones(1))
 
 
 def test_shard_range():
@@ -398,9 +405,9 @@ def test_minibatch_samplers_equal_one_big_batch(emu):
     utterances are independent, so with replayed noise the chunks reproduce the big batch."""
     import parity as P
     from oracle import ncsnpp_oracle as NO, synth
-    cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
+    cfg = NO.NetCfg.for_variant("ncsnpp", nf=32, image_size=64)      # a quarter of the frequency bins: this test is about the host wrappers
     m, _ = P.make_model(cfg, emu)
-    y = synth.synth_spec(3, 256, 64, seed=3)
+    y = synth.synth_spec(3, 64, 64, seed=3)
     N = 1
     full, nfe = m.get_pc_sampler("reverse_diffusion", "ald", y, N=N, snr=0.5, noise=P.replay_noise(y.shape, 1 + 2 * N))()
     assert nfe == 2 * N
