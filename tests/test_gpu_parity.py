@@ -351,6 +351,30 @@ def test_full_size_batch_independence(hip):
     assert torch.equal(net(x[perm].contiguous(), t[perm].contiguous()), full[perm])
 
 
+def test_maximum_batch_more_than_2_to_the_31_activation_elements(hip):
+    """Maximum sizes: 136 four-second utterances at full width are 136 x 128 x 256 x 512 = 2.28e9 activation elements per
+    tensor (past 2^31; 76 GB of arena out of 288 GB of HBM).  Utterances never interact, so the first, a middle and the last
+    one must equal their evaluation in a batch of three, bit for bit -- any 32-bit element index would show here."""
+    cfg = NO.NetCfg.for_variant("ncsnpp")
+    net, _ = P.make_backbone(cfg, hip)
+    g = torch.Generator().manual_seed(13)
+    B, pick = 136, [0, 70, 135]
+    x3 = (torch.randn(3, 2, 256, 512, dtype=torch.complex64, generator=g) * 0.3).to(hip)
+    t3 = torch.tensor([0.9, 0.4, 0.05], device=hip)
+    small = net(x3, t3)
+    x = (torch.randn(1, 2, 256, 512, dtype=torch.complex64, generator=g) * 0.3).to(hip).expand(B, -1, -1, -1).contiguous()
+    t = torch.full((B,), 0.5, device=hip)
+    for j, i in enumerate(pick):
+        x[i], t[i] = x3[j], t3[j]
+    big = net(x, t)
+    assert torch.isfinite(torch.view_as_real(big)).all()
+    for j, i in enumerate(pick):
+        assert torch.equal(big[i], small[j])
+    assert torch.equal(big[1], big[2])          # the filler utterances are copies of one another
+    del big, x
+    net(x3, t3)                                  # back to a small shape: the arena is re-planned (and stays allocated)
+
+
 def test_conv_tile_shape_never_changes_a_bit(hip):
     P.check_tile_independence(hip, "fwd_nf32")
 
