@@ -470,3 +470,22 @@ def test_bench_gpus_2_spawns_two_ranks(emu):
     assert d["collective_backend"]["world_size"] == 2 and len(d["per_rank_utt_per_s"]) == 2 and d["weight_broadcast_ms"] > 0
     assert d["config"]["batch_per_gpu"] == 1 and "TEST ONLY" in d["data"]
     assert abs(d["value"] - 2 * 1 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
+
+
+def test_bench_under_the_drivers_torch_distributed_run_line(emu):
+    """The launch line of the round-end scaling bench: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from
+    the environment, rank 0 prints the one JSON line.  (--test-emulator: CPU tensors, gloo, reduced-width network.)"""
+    import json
+    from conftest import EMU_LIB
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(SGMSE_EMU_THREADS="4", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29578", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--batch", "1", "--seconds", "0.5", "--N", "1", "--test-emulator", EMU_LIB],
+                         capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout + out.stderr
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["collective_backend"]["world_size"] == 2 and len(d["per_rank_utt_per_s"]) == 2
+    assert d["weight_broadcast_ms"] > 0 and d["scaling"] == "weak"
