@@ -180,7 +180,7 @@ def fir_down2(x):
     """downsample_2d(x, (1,3,3,1), factor=2) (up_or_down_sampling.py:227-257) =
     upfirdn2d(down=2, pad=(1,1)) with k = outer(taps)/64 (upfirdn2d.py:162-203).
     Closed form: out[i,j] = sum_ab k[a]k[b] x[2i+a-1, 2j+b-1], zero outside."""
-    k1 = torch.tensor(FIR_TAPS, dtype=x.dtype) / 8.0
+    k1 = torch.tensor(FIR_TAPS, dtype=x.dtype, device=x.device) / 8.0
     k2 = torch.outer(k1, k1)
     c = x.shape[1]
     w = k2.flip(0, 1)[None, None].expand(c, 1, 4, 4).contiguous()
@@ -191,10 +191,10 @@ def fir_down2(x):
 def fir_up2(x):
     """upsample_2d(x, (1,3,3,1), factor=2) (up_or_down_sampling.py:195-224) =
     zero-insert, pad (2,1), correlate with flipped k*4."""
-    k1 = torch.tensor(FIR_TAPS, dtype=x.dtype) / 8.0
+    k1 = torch.tensor(FIR_TAPS, dtype=x.dtype, device=x.device) / 8.0
     k2 = torch.outer(k1, k1) * 4.0
     b, c, h, w = x.shape
-    z = torch.zeros(b, c, 2 * h, 2 * w, dtype=x.dtype)
+    z = torch.zeros(b, c, 2 * h, 2 * w, dtype=x.dtype, device=x.device)
     z[:, :, ::2, ::2] = x
     zp = F.pad(z, (2, 1, 2, 1))
     wk = k2.flip(0, 1)[None, None].expand(c, 1, 4, 4).contiguous()
@@ -206,7 +206,7 @@ def upfirdn2d_ref(x, kernel, up=1, down=1, pad=(0, 0)):
     2-D kernel; same pad on both axes as the wrapper :148-159."""
     n, c, h, w = x.shape
     kh, kw = kernel.shape
-    z = torch.zeros(n, c, h * up, w * up, dtype=x.dtype)
+    z = torch.zeros(n, c, h * up, w * up, dtype=x.dtype, device=x.device)
     z[:, :, ::up, ::up] = x
     p0, p1 = pad
     z = F.pad(z, (max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)))

@@ -351,6 +351,49 @@ def test_full_size_batch_independence(hip):
     assert torch.equal(net(x[perm].contiguous(), t[perm].contiguous()), full[perm])
 
 
+def test_eager_torch_restatement_on_the_same_gpu(hip):
+    """What a PyTorch-ROCm user of the reference gets on this GPU without this library: the oracle is the reference's forward
+    restated in plain torch fp32 operators (F.conv2d -> MIOpen, group_norm, silu, softmax, einsum), so running it on `cuda`
+    is the eager path of the reference on an MI355X.  Parity GPU-vs-GPU at full width, and the two per-evaluation times,
+    printed (`pytest -s`; the log is committed under profiles/).  The time is a reported baseline, not a gate."""
+    import time
+    cfg = NO.NetCfg.for_variant("ncsnpp")
+    net, Pm = P.make_backbone(cfg, hip)
+    Pd = {k: v.to(hip) for k, v in Pm.items()}
+    g = torch.Generator().manual_seed(14)
+    B = 4
+    x = (torch.randn(B, 2, 256, 512, dtype=torch.complex64, generator=g) * 0.3).to(hip)
+    t = torch.tensor([0.9, 0.5, 0.2, 0.05], device=hip)
+    prev = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cudnn.allow_tf32 = torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        with torch.no_grad():
+            ref = NO.ncsnpp_forward(Pd, cfg, x, t)            # warm-up (MIOpen picks its kernels here)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                ref = NO.ncsnpp_forward(Pd, cfg, x, t)
+            torch.cuda.synchronize()
+            eager_ms = (time.perf_counter() - t0) / 2 * 1e3
+    finally:
+        torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = prev
+    out = net(x, t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        out = net(x, t)
+    torch.cuda.synchronize()
+    hip_ms = (time.perf_counter() - t0) / 2 * 1e3
+    with torch.no_grad():
+        cpu = NO.ncsnpp_forward(Pm, cfg, x.cpu(), t.cpu())      # the pinned oracle itself (CPU fp32)
+    e_hip, e_eager, e_between = rel_l2(out.cpu(), cpu), rel_l2(ref.cpu(), cpu), rel_l2(out.cpu(), ref.cpu())
+    print(f"full-width NCSN++ evaluation, batch {B}, on {torch.cuda.get_device_name(0)}: eager torch fp32 restatement "
+          f"{eager_ms:.1f} ms ({eager_ms / B:.1f} ms per utterance), HIP path {hip_ms:.1f} ms ({hip_ms / B:.1f} ms per utterance, "
+          f"eager launch, no graph) -> x{eager_ms / hip_ms:.1f}; rel_l2 vs the CPU oracle: HIP {e_hip:.3e}, eager torch on the GPU "
+          f"{e_eager:.3e}; between the two GPU results {e_between:.3e}")
+    assert e_hip < P.NET_TOL and e_between < 1e-4
+
+
 def test_maximum_batch_more_than_2_to_the_31_activation_elements(hip):
     """Maximum sizes: 136 four-second utterances at full width are 136 x 128 x 256 x 512 = 2.28e9 activation elements per
     tensor (past 2^31; 76 GB of arena out of 288 GB of HBM).  Utterances never interact, so the first, a middle and the last
