@@ -531,7 +531,7 @@ def check_enhancement_script(dev, tmp_path, monkeypatch):
     lengths = {"a.wav": 2000, "b.wav": 2000, "sub/c.wav": 2600}
     for name, L in lengths.items():
         wavfile.write(str(noisy / name), 16000, (0.1 * torch.randn(L, generator=rng)).numpy())
-    base = ["--test_dir", str(noisy), "--ckpt", str(ckpt), "--device", str(dev), "--N", "2", "--seed", "7"]
+    base = ["--test_dir", str(noisy), "--ckpt", str(ckpt), "--device", str(dev), "--N", "1", "--seed", "7"]
     with pytest.warns(UserWarning):          # checkpoint without EMA weights (model.py:106)
         assert E.main(base + ["--enhanced_dir", str(tmp_path / "o1")]) == 3
         assert E.main(base + ["--enhanced_dir", str(tmp_path / "o2"), "--batch_size", "2"]) == 3
@@ -580,7 +580,7 @@ def check_reference_script_unmodified(dev, tmp_path, monkeypatch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.syspath_prepend(os.path.join(root, "sgmse_amd", "compat"))
     sys.path.append(os.path.join(root, "sgmse_amd", "compat", "shims"))
-    args = ["--test_dir", str(noisy), "--ckpt", str(ckpt), "--device", str(dev), "--N", "2"]
+    args = ["--test_dir", str(noisy), "--ckpt", str(ckpt), "--device", str(dev), "--N", "1"]
     before = set(sys.modules)
     try:
         monkeypatch.setattr(sys, "argv", [ref] + args + ["--enhanced_dir", str(tmp_path / "ref_out")])
