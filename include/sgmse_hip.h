@@ -167,6 +167,16 @@ int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out);
  * different batch size): utterance b uses stream b.  Replaces nothing in the reference (torch.randn_like draws depend on the
  * global generator state, sdes.py:229, correctors.py:74, predictors.py:62). */
 int sgmse_set_noise_streams(sgmse_ctx* ctx, const unsigned long long* ids, int n);
+/* Ragged batches: frames[b] = number of spectrogram frames T_b of utterance b (host array; each a multiple of 2^(levels-1), i.e.
+ * of 64 -- what pad_spec produces) for ALL FOLLOWING sgmse_ncsnpp_forward / sgmse_pc_sample calls of batch size n, until the next
+ * call (n = 0: uniform batches again).  Those calls then take T = max_b T_b and PACKED tensors: utterance after utterance, each
+ * with its own row stride -- xy: [2][F][T_b] per utterance, y / the results: [F][T_b] per utterance (sum_b F*T_b complex elements).
+ * An utterance's result is bit-identical to the one its own single-utterance call gives (every kernel addresses an utterance's
+ * block exactly as in that call; which kernel family a layer uses depends on the U-Net level only, never on T), so a corpus of
+ * mixed lengths runs in full batches.  In-kernel noise only (noise == NULL), correctors "ald" / "none"; the Langevin corrector
+ * couples the utterances of a batch (correctors.py:50-52) and the Schroedinger-bridge sampler are not supported.
+ * Replaces the one-file-at-a-time loop of enhancement.py:57-103. */
+int sgmse_set_frames(sgmse_ctx* ctx, const int* frames, int n);
 /* how many times this context captured + instantiated a sampler step as a hipGraph (a run over many batches of one shape and
  * sampler configuration captures once: the Philox seed is device data, not a graph parameter) */
 int sgmse_graph_captures(sgmse_ctx* ctx, int* out);

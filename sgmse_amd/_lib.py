@@ -71,6 +71,7 @@ _SIGS = {
     "sgmse_arena_bytes": (_I, [_P, C.POINTER(_LL)]),
     "sgmse_graph_captures": (_I, [_P, C.POINTER(_I)]),
     "sgmse_set_noise_streams": (_I, [_P, C.POINTER(C.c_ulonglong), _I]),
+    "sgmse_set_frames": (_I, [_P, C.POINTER(_I), _I]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -250,10 +251,18 @@ class Context:
                   noise: Optional[torch.Tensor], seed: int, use_graph: bool = True, affine=None, snr: float = 0.0, streams=None):
         """``affine``: optional (in_scale, score_alpha, score_beta) fp32 tensors of length N: the score wrapper of
         ScoreModel.forward's new-code branch (ncsnpp_v2); None = old-code branch (score = -F)."""
-        Y = check_tensor(Y, "y", torch.complex64, self.device)
-        if Y.dim() != 4 or Y.shape[1] != 1:
-            raise ValueError(f"expected y of shape [B,1,F,T], got {tuple(Y.shape)}")
-        B, _, F_, T = Y.shape
+        frames = None
+        if isinstance(Y, (list, tuple)):       # ragged batch: utterances [F,T_b] (or [1,F,T_b]) of different lengths, see set_frames
+            if noise is not None:
+                raise ValueError("ragged batches use in-kernel noise only")
+            frames = [int(y.shape[-1]) for y in Y]
+            F_, B, T = int(Y[0].shape[-2]), len(Y), max(frames)
+            Y = torch.cat([check_tensor(y, "y", torch.complex64, self.device).reshape(-1) for y in Y])
+        else:
+            Y = check_tensor(Y, "y", torch.complex64, self.device)
+            if Y.dim() != 4 or Y.shape[1] != 1:
+                raise ValueError(f"expected y of shape [B,1,F,T], got {tuple(Y.shape)}")
+            B, _, F_, T = Y.shape
         N = int(table["t"].numel())
         cfg = SamplerCfgC()
         cfg.N = N
@@ -288,8 +297,14 @@ class Context:
 
         def run():
             self.use_current_stream()
-            self.check(self.lib.sgmse_pc_sample(self.h, Y.data_ptr(), out.data_ptr(), B, F_, T, C.byref(cfg), ptr(noise),
-                                                C.c_ulonglong(seed & (2 ** 64 - 1)), C.byref(nfe)))
+            if frames is not None:
+                self.set_frames(frames)
+            try:
+                self.check(self.lib.sgmse_pc_sample(self.h, Y.data_ptr(), out.data_ptr(), B, F_, T, C.byref(cfg), ptr(noise),
+                                                    C.c_ulonglong(seed & (2 ** 64 - 1)), C.byref(nfe)))
+            finally:
+                if frames is not None:
+                    self.set_frames([])
 
         cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         if cur is not None and use_graph and cur.cuda_stream == 0:
@@ -304,6 +319,12 @@ class Context:
         else:
             run()
         self._keep["sampler"] = (noise, keep)   # the captured graph refers to the replayed-noise buffer
+        if frames is not None:                  # unpack: one [1,F,T_b] tensor per utterance
+            outs, o = [], 0
+            for T_b in frames:
+                outs.append(out[o:o + F_ * T_b].reshape(1, F_, T_b))
+                o += F_ * T_b
+            return outs, nfe.value
         return out, nfe.value
 
     def sb_sample(self, Y: torch.Tensor, table: Dict[str, torch.Tensor], *, stochastic: bool, noise: Optional[torch.Tensor],
@@ -378,6 +399,34 @@ class Context:
         ids = [int(v) & (2 ** 64 - 1) for v in (ids.tolist() if hasattr(ids, "tolist") else ids)]
         arr = (C.c_ulonglong * len(ids))(*ids)
         self.check(self.lib.sgmse_set_noise_streams(self.h, arr, len(ids)))
+
+    def set_frames(self, frames) -> None:
+        """Ragged batches (sgmse_set_frames): frame count of every utterance of the following calls; [] = uniform batches again."""
+        frames = [int(v) for v in frames]
+        arr = (_I * max(len(frames), 1))(*frames)
+        self.check(self.lib.sgmse_set_frames(self.h, arr if frames else None, len(frames)))
+
+    def forward_ragged(self, xys, t: torch.Tensor):
+        """NCSNpp.forward on utterances of different lengths in ONE batch: xys = list of complex64 [2,F,T_b]; returns the list of
+        complex64 [1,F,T_b], each bit-identical to ``forward(xy[None], t[b:b+1])[0]``."""
+        frames = [int(x.shape[-1]) for x in xys]
+        F_ = int(xys[0].shape[-2])
+        packed = torch.cat([check_tensor(x, "x", torch.complex64, self.device).reshape(-1) for x in xys])
+        t = check_tensor(t.reshape(-1), "time_cond", torch.float32, self.device)
+        if t.numel() != len(xys):
+            raise ValueError("time_cond must have one entry per utterance")
+        out = torch.empty(F_ * sum(frames), dtype=torch.complex64, device=self.device)
+        self.set_frames(frames)
+        try:
+            self.use_current_stream()
+            self.check(self.lib.sgmse_ncsnpp_forward(self.h, packed.data_ptr(), t.data_ptr(), out.data_ptr(), len(xys), F_, max(frames)))
+        finally:
+            self.set_frames([])
+        outs, o = [], 0
+        for T_b in frames:
+            outs.append(out[o:o + F_ * T_b].reshape(1, F_, T_b))
+            o += F_ * T_b
+        return outs
 
     def graph_captures(self) -> int:
         """Number of hipGraph captures (+ instantiations) of a sampler step this context has done."""

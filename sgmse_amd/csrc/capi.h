@@ -205,6 +205,11 @@ int sgmse_set_noise_streams(sgmse_ctx* ctx, const unsigned long long* ids, int n
   return sg_guard(ctx, [&](sgmse::Engine& e) { e.set_noise_streams(ids, n); });
 }
 
+int sgmse_set_frames(sgmse_ctx* ctx, const int* frames, int n) {
+  SG_ARG(ctx, (frames != nullptr && n > 0) || n == 0, "bad frame table");
+  return sg_guard(ctx, [&](sgmse::Engine& e) { e.set_ragged_frames(frames, n); });
+}
+
 int sgmse_graph_captures(sgmse_ctx* ctx, int* out) {
   SG_ARG(ctx, out != nullptr, "out is null");
   return sg_guard(ctx, [&](sgmse::Engine& e) { *out = e.graph_captures(); });

@@ -34,7 +34,7 @@ inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant,
   const int tiles = a.B * ((a.H + T::ROWS - 1) / T::ROWS) * ((a.W + 31) / 32);
   dim3 grid(tiles, (a.Cout + T::CO_T - 1) / T::CO_T, ksplit);
   if (variant < 0) variant = conv_variant();
-  const bool vec = (a.W % 4 == 0) && !(variant & 2) && (reinterpret_cast<uintptr_t>(a.src1) % 16 == 0) &&
+  const bool vec = (a.rag_w ? a.rag_vec_ok != 0 : a.W % 4 == 0) && !(variant & 2) && (reinterpret_cast<uintptr_t>(a.src1) % 16 == 0) &&
                    (a.src2 == nullptr || reinterpret_cast<uintptr_t>(a.src2) % 16 == 0);
   const bool pref = !(variant & 1);
   if constexpr (FC * FP == 8) {

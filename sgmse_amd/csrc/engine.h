@@ -377,6 +377,7 @@ class Engine {
     const float* bias_table; int bias_bstride, bias_sstride; const int* step_ptr;
     const float* tvals; int t_bstride, t_sstride; float sign;
     const float* coef = nullptr; int coef_bstride = 0, coef_sstride = 0;   // score-wrapper rows {gamma, alpha, beta, -} or null
+    int y_plane = 0;     // ragged launches: y of utterance b lies y_plane * F * T_b elements behind its x-relative position (entry_kernel)
   };
 
   void forward_xy(const float2* xy, const float* t_dev, float2* out, int B, int F, int T) {
@@ -387,7 +388,12 @@ class Engine {
     FwdCtl ctl{bias_table_, tot_temb_, 0, nullptr, t_dev, 1, 0, 1.0f};
     const long long FT = (long long)F * T;
     arena_.reset();
-    run_forward(xy, 2 * FT, xy + FT, 2 * FT, out, B, F, T, ctl);
+    if (ragged()) {          // xy: utterance after utterance, each [2][F][T_b]; out: each [F][T_b]
+      ctl.y_plane = 1;
+      run_forward(xy, 2, xy, 2, out, B, F, T, ctl);
+    } else {
+      run_forward(xy, 2 * FT, xy + FT, 2 * FT, out, B, F, T, ctl);
+    }
   }
 
   // ---- sampler --------------------------------------------------------------------------------------------------
@@ -397,7 +403,9 @@ class Engine {
     SG_REQUIRE(sc.N >= 1 && sc.t && sc.dt && sc.G && sc.G2, "pc_sample: step table missing");
     SG_REQUIRE(sc.corrector != 1 || (sc.ald_eps && sc.ald_noise), "pc_sample: ALD table missing");
     ensure_shape(B, F, T, sc.N);
-    const size_t n = (size_t)B * F * T;
+    SG_REQUIRE(!ragged() || sc.corrector != 2, "ragged batches: the Langevin corrector couples the utterances of a batch (correctors.py:50-52) and is not supported");
+    SG_REQUIRE(!ragged() || !noise, "ragged batches: replayed noise is not supported (in-kernel noise only)");
+    const size_t n = ragged() ? rag_pix_[0] : (size_t)B * F * T;     // complex elements of Y / the result, utterance after utterance
     // step table -> device
     std::vector<float> tab((size_t)sc.N * SC_STRIDE, 0.f), tv(sc.N);
     for (int i = 0; i < sc.N; ++i) {
@@ -429,6 +437,7 @@ class Engine {
     sa.table = step_table_; sa.step_ptr = step_ctr_; sa.theta = sc.theta; sa.std1 = sc.std1; sa.n = (int)n;
     sa.score_w = sc.probability_flow ? 0.5f : 1.0f;
     sa.snr = sc.snr; sa.B = B; sa.per = F * T; sa.partial = lang_partial_; sa.lang = lang_scal_;
+    sa.rag_off = ragged() ? rag_off_dev_[0] : nullptr;
     const dim3 eg((unsigned)((n + 255) / 256));
 
     sa.draw_base = 0; sa.draw_per_step = 0;
@@ -438,7 +447,7 @@ class Engine {
 
     FwdCtl ctl{bias_table_, 0, tot_temb_, step_ctr_, tsteps_, 0, 1, -1.0f};
     if (affine) { ctl.coef = coef_table_; ctl.coef_bstride = 0; ctl.coef_sstride = 1; }
-    const long long FT = (long long)F * T;
+    const long long FT = ragged() ? 1 : (long long)F * T;          // batch stride of x / y (ragged: multiplier of the utterance's offset)
     auto step_body = [&]() {
       for (int cs = 0; cs < ncorr; ++cs) {
         arena_.reset();
@@ -464,7 +473,7 @@ class Engine {
     };
 
     GraphKey key{B, F, T, sc.corrector, ncorr, sc.predictor, sc.probability_flow + (affine ? 2 : 0), (const void*)Y, (const void*)noise,
-                 sc.theta + 1000.f * sc.snr * (sc.corrector == 2), draws_per_step};
+                 sc.theta + 1000.f * sc.snr * (sc.corrector == 2), draws_per_step};      // (set_frames invalidates the graph itself)
     const bool want_graph = sc.use_graph && drt::graphs_supported();
     if (want_graph) {
       if (!graph_valid_ || !(key == graph_key_)) {
@@ -489,6 +498,7 @@ class Engine {
                  const float2* noise, unsigned long long seed, int use_graph) {
     require_ready();
     SG_REQUIRE(N >= 1 && t && w_prev && w_est && w_y && w_z, "sb_sample: step table missing");
+    SG_REQUIRE(!ragged(), "ragged batches: not supported by the Schroedinger-bridge sampler");
     ensure_shape(B, F, T, N);
     const size_t n = (size_t)B * F * T;
     std::vector<float> tab((size_t)N * SC_STRIDE, 0.f), tv(N);
@@ -544,6 +554,7 @@ class Engine {
     nfe_ = N;
   }
   void set_noise_streams(const unsigned long long* ids, int n) { streams_next_.assign(ids, ids + n); }
+  void set_ragged_frames(const int* frames, int n) { set_frames(frames, n); }     // sgmse_set_frames
   int last_nfe() const { return nfe_; }
   int graph_captures() const { return graph_captures_; }     // how many times a step was captured + instantiated (tests, bench)
   int split_mode() const { return split_mode_; }
@@ -615,11 +626,11 @@ class Engine {
     float* sc = static_cast<float*>(dev_alloc_tmp((size_t)B * C * 4));
     float* sh = static_cast<float*>(dev_alloc_tmp((size_t)B * C * 4));
     float* stats2 = stats + (size_t)B * C1 * 2;
-    DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C1), dim3(256), stream_, x, (const float*)nullptr, C1, 0, HW, stats);
-    if (C2) DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C2), dim3(256), stream_, x2, (const float*)nullptr, C2, 0, HW, stats2);
+    DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C1), dim3(256), stream_, x, (const float*)nullptr, C1, 0, HW, stats, Rag{nullptr, nullptr, nullptr}, 0);
+    if (C2) DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C2), dim3(256), stream_, x2, (const float*)nullptr, C2, 0, HW, stats2, Rag{nullptr, nullptr, nullptr}, 0);
     const int G = std::min(C / 4, 32);
     DRT_LAUNCH(gn_finalize_kernel, dim3(G, B), dim3(256), stream_, (const float*)stats, C1, 1, (const float*)stats2, C2, 1, gamma, beta, G,
-               HW, 1e-6f, sc, sh);
+               HW, 1e-6f, sc, sh, Rag{nullptr, nullptr, nullptr}, 0);
     DRT_LAUNCH(gn_apply_kernel, dim3((HW + 1023) / 1024, B * C), dim3(256), stream_, x, x2, C1, C2, HW, (const float*)sc,
                (const float*)sh, act, out);
     SG_CHECK(drt::stream_sync(stream_));
@@ -629,7 +640,7 @@ class Engine {
 
   void op_fir(const float* x, float* out, int BC, int H, int W, int up, const float* in_scale, const float* in_shift, int in_act,
               float* out_raw) {
-    FirArgs fa{x, out, in_scale, in_shift, in_act, BC, H, W, out_raw};
+    FirArgs fa{x, out, in_scale, in_shift, in_act, BC, H, W, out_raw, 1, Rag{nullptr, nullptr, nullptr}};
     launch_fir(fa, up);
     check_launch();
   }
@@ -645,7 +656,7 @@ class Engine {
   }
 
   void op_attention(const float* qkv, float* out, int B, int C, int S) {
-    AttnArgs a{qkv, out, B, C, S, 1.0f / sqrtf((float)C)};
+    AttnArgs a{qkv, out, B, C, S, 1.0f / sqrtf((float)C), Rag{nullptr, nullptr, nullptr}, 0};
     SG_REQUIRE(launch_attn_core(a, stream_), "attention: C must be 32, 64, 128 or 256");
     check_launch();
   }
@@ -975,8 +986,10 @@ class Engine {
     SG_REQUIRE(B >= 1 && F >= 1 && T >= 1, "bad shape");
     const int down = 1 << (cfg_.n_levels - 1);
     SG_REQUIRE(F % down == 0 && T % down == 0, "F and T must be multiples of 2^(levels-1) (pad_spec pads T to a multiple of 64)");
-    if (B != shape_B_ || F != shape_F_ || T != shape_T_) {
+    if (B != shape_B_ || F != shape_F_ || T != shape_T_ || (ragged() && !rag_built_)) {
       invalidate_graph();
+      cur_F_ = F;
+      if (ragged()) build_rag_tables(B, F, T);
       // size the arena by a dry run
       for (int attempt = 0; attempt < 2; ++attempt) {
         arena_.measure_mode();
@@ -998,7 +1011,7 @@ class Engine {
         arena_cap_ = need;
       }
       arena_.configure(arena_base_, arena_cap_);
-      const size_t n = (size_t)B * F * T;
+      const size_t n = (size_t)B * F * T;      // (a ragged batch needs at most this)
       if (n > samp_n_) {
         for (float2** q : {&sx_, &sxm_, &sscore_, &sy_}) { if (*q) dev_free_owned(*q); *q = static_cast<float2*>(dev_alloc(n * 8)); }
         samp_n_ = n;
@@ -1057,7 +1070,69 @@ class Engine {
   }
   void tock() { if (prof_) { if (!ev_init_) { drt::event_create(&ev_a_); drt::event_create(&ev_b_); ev_init_ = true; } drt::event_record(&ev_a_, stream_); } }
 
-  Tensor new_tensor(int C, int H, int W) { Tensor t; t.C = C; t.H = H; t.W = W; t.p = arena_.alloc((size_t)B_ * C * H * W); return t; }
+  Tensor new_tensor(int C, int H, int W) { Tensor t; t.C = C; t.H = H; t.W = W; t.p = arena_.alloc((size_t)C * pix_total(H, W)); return t; }
+
+  // ---- ragged batches (set_frames): utterances of different frame counts in one launch ------------------------------------
+  // Every activation tensor holds utterance b's planes with its own row stride, packed one utterance after the other; the
+  // per-level tables below give each kernel an utterance's width and first pixel (Rag, kernels_conv.h).  Which kernel FAMILY a
+  // layer runs on is decided from the level alone (dec_W: the width a 512-frame utterance has there), never from the actual
+  // widths: an utterance then goes through the same kernels, with the same arithmetic, alone, in a uniform batch or in a
+  // ragged one.
+  static constexpr int kNominalFrames = 512;
+  bool ragged() const { return !rag_T_.empty(); }
+  int level_of(int H) const { int l = 0; while ((cur_F_ >> l) > H && l < 30) ++l; return l; }
+  int dec_W(int H) const { return std::max(1, kNominalFrames >> level_of(H)); }
+  size_t pix_total(int H, int W) const { return ragged() ? rag_pix_.at(level_of(H)) : (size_t)B_ * H * W; }
+  Rag rag_of(int H) const {
+    if (!ragged()) return Rag{nullptr, nullptr, nullptr};
+    const int l = level_of(H);
+    return Rag{rag_w_dev_.at(l), rag_off_dev_.at(l), rag_soff_dev_.at(l)};
+  }
+  bool rag_all_mult4(int H) const {
+    if (!ragged()) return true;
+    const int l = level_of(H);
+    for (int t : rag_T_) if ((t >> l) % 4) return false;
+    return true;
+  }
+  void set_frames(const int* frames, int n) {          // n == 0: uniform batches again
+    std::vector<int> v(frames, frames + n);
+    if (v != rag_T_) { rag_T_ = v; rag_built_ = false; shape_B_ = 0; invalidate_graph(); }
+  }
+  void build_rag_tables(int B, int F, int T) {
+    const int L = cfg_.n_levels, down = 1 << (L - 1);
+    SG_REQUIRE((int)rag_T_.size() == B, "ragged batch: sgmse_set_frames gave a different number of utterances");
+    int tmax = 0;
+    for (int t : rag_T_) { SG_REQUIRE(t >= down && t % down == 0, "ragged batch: frame counts must be multiples of 2^(levels-1)"); tmax = std::max(tmax, t); }
+    SG_REQUIRE(tmax == T, "ragged batch: T must be the largest frame count");
+    for (void* q : rag_owned_) dev_free_owned(q);
+    rag_owned_.clear(); rag_w_dev_.clear(); rag_off_dev_.clear(); rag_soff_dev_.clear(); rag_pix_.clear();
+    for (int l = 0; l < L; ++l) {
+      const int H = F >> l;
+      std::vector<int> w(B);
+      std::vector<long long> off(B + 1, 0), soff(B + 1, 0);
+      for (int b = 0; b < B; ++b) {
+        w[b] = rag_T_[b] >> l;
+        off[b + 1] = off[b] + (long long)H * w[b];
+        soff[b + 1] = soff[b] + (long long)H * ((w[b] + 31) / 32);
+      }
+      int* wd = static_cast<int*>(dev_alloc((size_t)B * 4));
+      long long* od = static_cast<long long*>(dev_alloc((size_t)(B + 1) * 8));
+      long long* sd = static_cast<long long*>(dev_alloc((size_t)(B + 1) * 8));
+      SG_CHECK(drt::memcpy_h2d(wd, w.data(), (size_t)B * 4, stream_));
+      SG_CHECK(drt::memcpy_h2d(od, off.data(), (size_t)(B + 1) * 8, stream_));
+      SG_CHECK(drt::memcpy_h2d(sd, soff.data(), (size_t)(B + 1) * 8, stream_));
+      SG_CHECK(drt::stream_sync(stream_));
+      rag_owned_.push_back(wd); rag_owned_.push_back(od); rag_owned_.push_back(sd);
+      rag_w_dev_.push_back(wd); rag_off_dev_.push_back(od); rag_soff_dev_.push_back(sd);
+      rag_pix_.push_back((size_t)off[B]);
+    }
+    rag_built_ = true;
+  }
+  std::vector<int> rag_T_;
+  std::vector<int*> rag_w_dev_; std::vector<long long*> rag_off_dev_, rag_soff_dev_; std::vector<size_t> rag_pix_;
+  std::vector<void*> rag_owned_;
+  bool rag_built_ = false;
+  int cur_F_ = 0;
   void drop(Tensor& t) { arena_.release(t.p); t.p = nullptr; if (t.st) { arena_.release(t.st); t.st = nullptr; } }
 
   // GroupNorm coefficients of the virtual concat [a | b].  Per-channel partial sums come from the producing convolution's
@@ -1076,7 +1151,7 @@ class Engine {
       if (!dry_) {
         tock();
         DRT_LAUNCH(gn_chan_stats_kernel, dim3(B_ * src[k]->C), dim3(256), stream_, (const float*)src[k]->p, (const float*)nullptr,
-                   src[k]->C, 0, HW, tmp[k]);
+                   src[k]->C, 0, HW, tmp[k], rag_of(a.H), a.H);
         if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "gn_chan_stats C=%d @%dx%dx%d", src[k]->C, B_, a.H, a.W);
         tick(TC_GN, 4.0 * B_ * (double)src[k]->C * HW, 1);
       }
@@ -1087,7 +1162,7 @@ class Engine {
       tock();
       const int G = std::min(C / 4, 32);
       DRT_LAUNCH(gn_finalize_kernel, dim3(G, B_), dim3(256), stream_, st[0], a.C, nsub[0], st[1], b ? b->C : 0, nsub[1], gamma, beta, G,
-                 HW, 1e-6f, *sc, *sh);
+                 HW, 1e-6f, *sc, *sh, rag_of(a.H), a.H);
       if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "gn_finalize C=%d nsub=%d @%dx%dx%d", C, nsub[0], B_, a.H, a.W);
       tick(TC_GN, 8.0 * B_ * ((double)a.C * nsub[0] + (b ? (double)b->C * nsub[1] : 0.0)), 1);
     }
@@ -1132,14 +1207,15 @@ class Engine {
     }
     // fp32-accurate bf16x3 kernel for the wide levels.  Decided per layer and per IMAGE (never by the batch size), because
     // its results differ from the fp32-MFMA kernels in the last bits and an utterance must not depend on its batch.
-    const long tiles8 = (long)((a.H + 7) / 8) * ((a.W + 31) / 32);
+    const int Wd = dec_W(a.H);          // family decisions by the level, not by the utterance length (see dec_W)
+    const long tiles8 = (long)((a.H + 7) / 8) * ((Wd + 31) / 32);
     // Levels with 2..chunk_max_tiles_ tiles per image (16 x 32, 32 x 64): the fp16x2 split kernel in its 4-row shape with CHUNKED
     // accumulation, so that a small batch can spread the chunks over workgroups (split-K, bit-identical) instead of running 16-32
     // serial stages on 8-32 workgroups; full 3x3 blocks behind a GroupNorm producer only (not the launches with a folded
     // shortcut).  Decided per layer and image size, never by the batch: chunking fixes the summation order.
     const bool coarse_split = coarse_split_ && use_mfma && w.packed_split && w.split_mode == 2 && w.ks == 3 && w.cout > 32 && !sc &&
                               conv_split_eligible(3, a.C, b ? b->C : 0, w.cout) && tiles8 >= chunk_min_tiles_ && tiles8 <= chunk_max_tiles_ &&
-                              a.W >= chunk_min_width_ &&
+                              Wd >= chunk_min_width_ &&
                               (xf.scale != nullptr || xf.bounded);
     const bool use_split = coarse_split || (use_mfma && w.packed_split &&
                         (conv_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout) || conv_thin_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout)) &&
@@ -1161,10 +1237,10 @@ class Engine {
       const long nblk = (long)B_ * ((a.H + 3) / 4) * ((a.W + 31) / 32) * (w.cout / 128);
       if (nchunks > 1 && nblk * coarse_splitk_div_ <= tile_min_blocks_) {
         ksplit = nchunks;
-        partial = arena_.alloc((size_t)nchunks * B_ * w.cout * a.H * a.W);
+        partial = arena_.alloc((size_t)nchunks * w.cout * pix_total(a.H, a.W));
       }
     }
-    if (use_mfma && !use_split && coarse_chunked_ && (long)a.H * a.W <= 512 && (w.co_t == 32 || w.packed32)) {
+    if (use_mfma && !use_split && coarse_chunked_ && (long)a.H * Wd <= 512 && (w.co_t == 32 || w.packed32)) {
       co_t = 32;
       const long nblk8 = (long)B_ * ((a.H + 7) / 8) * ((a.W + 31) / 32) * ((w.cout + 31) / 32);
       rows_ = (a.H >= 8 && nblk8 >= tile_min_blocks_) ? 8 : 4;
@@ -1174,7 +1250,7 @@ class Engine {
       const long nblk = (long)B_ * ((a.H + rows_ - 1) / rows_) * ((a.W + 31) / 32) * ((w.cout + 31) / 32);
       if (nchunks > 1 && nblk * 2 <= tile_min_blocks_) {
         ksplit = nchunks;
-        partial = arena_.alloc((size_t)nchunks * B_ * w.cout * a.H * a.W);
+        partial = arena_.alloc((size_t)nchunks * w.cout * pix_total(a.H, a.W));
       }
     }
     if (emit_stats && use_mfma && fuse_gn_stats_) {
@@ -1196,6 +1272,11 @@ class Engine {
     ca.step_ptr = bias2 ? ctl.step_ptr : nullptr;
     ca.in_scale = xf.scale; ca.in_shift = xf.shift; ca.in_act = xf.act;
     ca.res = res; ca.out_scale = out_scale; ca.out = o.p; ca.Cout = w.cout; ca.B = B_; ca.H = a.H; ca.W = a.W;
+    if (ragged()) {
+      const Rag rg = rag_of(a.H);
+      ca.rag_w = rg.w; ca.rag_off = rg.off; ca.rag_soff = rg.soff; ca.rag_slab = (long long)w.cout * (long long)pix_total(a.H, a.W);
+      ca.rag_vec_ok = rag_all_mult4(a.H) ? 1 : 0;
+    }
     tock();
     double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
     if (sc) {
@@ -1247,7 +1328,7 @@ class Engine {
       if (o.st) {
         tock();
         DRT_LAUNCH(gn_chan_stats_kernel, dim3(B_ * w.cout), dim3(256), stream_, (const float*)o.p, (const float*)nullptr, w.cout, 0,
-                   a.H * a.W, o.st);
+                   a.H * a.W, o.st, rag_of(a.H), a.H);
         if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "gn_chan_stats(direct) C=%d @%dx%dx%d", w.cout, B_, a.H, a.W);
         tick(TC_GN, 4.0 * B_ * (double)w.cout * a.H * a.W, 1);
       }
@@ -1255,9 +1336,11 @@ class Engine {
     return o;
   }
 
-  void launch_fir(const FirArgs& fa, bool up) {
+  void launch_fir(const FirArgs& fa, bool up, bool by_level = false) {
     const int H = fa.H, W = fa.W, BC = fa.BC;
-    if (fir_use_tiled(W) && !fir_scalar_) {
+    // tiled or per-pixel kernel: by the LEVEL (dec_W) inside the network, so that an utterance's FIR never depends on its length
+    const bool tiled = by_level ? (W % 4 == 0 && dec_W(H) >= 64 && rag_all_mult4(H)) : fir_use_tiled(W);
+    if (tiled && !fir_scalar_) {
       if (up) DRT_LAUNCH(fir_up2_tiled_kernel, dim3(((W + 63) / 64) * ((H + 7) / 8), BC), dim3(256), stream_, fa);
       else DRT_LAUNCH(fir_down2_tiled_kernel, dim3(((W / 2 + 63) / 64) * ((H / 2 + 7) / 8), BC), dim3(256), stream_, fa);
     } else {
@@ -1274,9 +1357,9 @@ class Engine {
       raw->amax = a.amax;      // the [1,3,3,1] resamplers are convex combinations (per output phase): max|FIR(x)| <= max|x|
     }
     if (dry_) return o;
-    FirArgs fa{a.p, o.p, xf.scale, xf.shift, xf.act, B_ * a.C, a.H, a.W, raw ? raw->p : nullptr};
+    FirArgs fa{a.p, o.p, xf.scale, xf.shift, xf.act, B_ * a.C, a.H, a.W, raw ? raw->p : nullptr, a.C, rag_of(a.H)};
     tock();
-    launch_fir(fa, up);
+    launch_fir(fa, up, true);
     if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "fir-%s C=%d @%dx%dx%d%s", up ? "up" : "down", a.C, B_, a.H, a.W, raw ? " +raw" : "");
     tick(TC_FIR, 4.0 * B_ * (double)a.C * (a.H * a.W + (raw ? 2.0 : 1.0) * o.H * o.W));
     return o;
@@ -1308,7 +1391,7 @@ class Engine {
     if (r.has_c2) {
       const Tensor& sa = have_xs ? xs : a;
       const Tensor* sb = have_xs ? nullptr : b;
-      if (runs_on_h2_split3(r.c1, h.C, h.H, h.W) && shortcut_foldable(r.c2, sa, sb)) {
+      if (runs_on_h2_split3(r.c1, h.C, h.H, dec_W(h.H)) && shortcut_foldable(r.c2, sa, sb)) {
         // (Conv_1(h) + Conv_2(x)) / sqrt 2 as one accumulation: the shortcut's K-stages run inside the 3x3 launch
         const Shortcut scin{&r.c2, &sa, sb};
         out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, nullptr, inv_sqrt2, ctl, true, &scin);
@@ -1336,7 +1419,7 @@ class Engine {
     arena_.release(sc); arena_.release(sh);
     Tensor o = new_tensor(x.C, x.H, x.W);
     if (!dry_) {
-      AttnArgs aa{qkv.p, o.p, B_, x.C, x.H * x.W, 1.0f / sqrtf((float)x.C)};
+      AttnArgs aa{qkv.p, o.p, B_, x.C, x.H * x.W, 1.0f / sqrtf((float)x.C), rag_of(x.H), x.H};
       tock();
       SG_REQUIRE(launch_attn_core(aa, stream_), "attention: unsupported channel count");
       if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "attention C=%d S=%d B=%d", x.C, x.H * x.W, B_);
@@ -1352,6 +1435,7 @@ class Engine {
   void run_forward(const float2* x, long long xbs, const float2* y, long long ybs, float2* out, int B, int F, int T,
                    const FwdCtl& ctl) {
     B_ = B;
+    cur_F_ = F;
     amax_next_ = 0;
     if (!dry_ && poison_ && arena_base_) SG_CHECK(drt::memset_dev(arena_base_, 0xFF, arena_cap_, stream_));
     if (!dry_ && amax_pool_) {
@@ -1370,7 +1454,7 @@ class Engine {
     if (entry8) xr8 = new_tensor(entry8_.cin, F, T);   // the same four planes + planes of zeros: one K-stage of the MFMA kernel
     if (!dry_) { tock(); const WrapCoef wc{ctl.coef, ctl.coef_bstride, ctl.coef_sstride, ctl.step_ptr, ctl.sign};
       DRT_LAUNCH(entry_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, x, xbs, y, ybs, xr.p, entry8 ? xr8.p : (float*)nullptr,
-                 entry8 ? entry8_.cin : 0, FT, wc);
+                 entry8 ? entry8_.cin : 0, FT, wc, rag_of(F), F, ctl.y_plane);
       tick(TC_MISC, (32.0 + (entry8 ? 4.0 * entry8_.cin : 0.0)) * B * FT); }
     std::vector<Tensor> hs;
     {
@@ -1472,7 +1556,7 @@ class Engine {
     if (!dry_) {
       ExitArgs ea{h4.p, Wp("output_layer.weight"), Wp("output_layer.bias"), ctl.tvals, ctl.t_bstride, ctl.t_sstride, ctl.step_ptr,
                   c.variant == 1 ? 1 : 0, c.scale_by_sigma,
-                  WrapCoef{ctl.coef, ctl.coef_bstride, ctl.coef_sstride, ctl.step_ptr, ctl.sign}, x, xbs, out, FT};
+                  WrapCoef{ctl.coef, ctl.coef_bstride, ctl.coef_sstride, ctl.step_ptr, ctl.sign}, x, xbs, out, FT, rag_of(F), F};
       tock();
       DRT_LAUNCH(exit_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, ea);
       tick(TC_MISC, 24.0 * B * FT);

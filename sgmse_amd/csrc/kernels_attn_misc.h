@@ -24,7 +24,7 @@ namespace sgmse {
 //      wave-private LDS tile with rows padded to 33 floats (bank = channel + key: conflict-free both ways) in chunks of 64
 //      channels; the A operand of P.V (lane = channel) is then one ds_read_b32.
 // LDS: q 32 KB + 4 x 8.4 KB (C = 256) = 66 KB and at most 256 registers: two workgroups per CU.
-struct AttnArgs { const float* qkv; float* out; int B, C, S; float scale; };
+struct AttnArgs { const float* qkv; float* out; int B, C, S; float scale; Rag rag; int H; };   // rag.w: S of utterance b = H * rag.w[b]
 
 template <int CF>
 __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnArgs p) {
@@ -38,9 +38,11 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnArgs p) {
   __shared__ float s_l[4][32];
   __shared__ float s_lt[32];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
-  const int S = p.S;
   const int b = blockIdx.y, s0 = blockIdx.x * 32;
-  const float* q = p.qkv + (size_t)b * 3 * C * S;
+  const int S = p.rag.w ? p.H * p.rag.w[b] : p.S;                  // ragged launch: the grid covers the longest utterance
+  if (s0 >= S) return;
+  const size_t pix0 = p.rag.w ? (size_t)p.rag.off[b] : (size_t)b * S;
+  const float* q = p.qkv + pix0 * 3 * C;
   const float* k = q + (size_t)C * S;
   const float* v = k + (size_t)C * S;
   const int nkt = (S + 31) / 32;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(AttnArgs p) {
   }
   for (int e = tid; e < C * 32; e += 256) {
     const int ch = e >> 5, j = e & 31;
-    if (s0 + j < S) p.out[((size_t)b * C + ch) * S + s0 + j] = s_O[e] / s_lt[j];
+    if (s0 + j < S) p.out[(pix0 * C + (size_t)ch * S) + s0 + j] = s_O[e] / s_lt[j];
   }
 }
 
@@ -266,19 +268,26 @@ __device__ __forceinline__ void wrap_coef(const WrapCoef& w, int b, float* gamma
 
 // Network entry (ncsnpp.py:262-263 / ncsnpp_v2.py:247): complex x_t, y -> real [B][4][F*T] = gamma*(x.re, x.im, y.re, y.im).
 // xr8 (optional): the same planes in a C8-channel tensor whose other channels are zero (input of the entry convolution on the MFMA kernels)
+// Ragged launch (rag.w): utterance b has FT_b = F * rag.w[b] elements; x_b = x + rag.off[b] * xbs, y_b = y + rag.off[b] * ybs +
+// y_plane * FT_b (xbs = ybs = 1 for the sampler's packed arrays; 2, 2 and y_plane = 1 for a packed [B][2][F][T_b] network input).
 __global__ __launch_bounds__(256) void entry_kernel(const float2* x, long long xbs, const float2* y, long long ybs,
-                                                    float* xr, float* xr8, int C8, int FT, WrapCoef w) {
+                                                    float* xr, float* xr8, int C8, int FT, WrapCoef w, Rag rag, int F, int y_plane) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= FT) return;
   const int b = blockIdx.y;
+  size_t xo = (size_t)b * xbs, yo = (size_t)b * ybs, po = (size_t)b * FT;
+  if (rag.w) {
+    FT = F * rag.w[b];
+    xo = (size_t)rag.off[b] * xbs; yo = (size_t)rag.off[b] * ybs + (size_t)y_plane * FT; po = (size_t)rag.off[b];
+  }
+  if (i >= FT) return;
   float g, al, be;
   wrap_coef(w, b, &g, &al, &be);
-  const float2 xv = x[(size_t)b * xbs + i], yv = y[(size_t)b * ybs + i];
-  float* o = xr + (size_t)b * 4 * FT + i;
+  const float2 xv = x[xo + i], yv = y[yo + i];
+  float* o = xr + po * 4 + i;
   const float v0 = g * xv.x, v1 = g * xv.y, v2 = g * yv.x, v3 = g * yv.y;
   o[0] = v0; o[FT] = v1; o[2 * (size_t)FT] = v2; o[3 * (size_t)FT] = v3;
   if (xr8) {
-    float* q = xr8 + (size_t)b * C8 * FT + i;
+    float* q = xr8 + po * C8 + i;
     q[0] = v0; q[FT] = v1; q[2 * (size_t)FT] = v2; q[3 * (size_t)FT] = v3;
     for (int k = 4; k < C8; ++k) q[(size_t)k * FT] = 0.f;
   }
@@ -293,18 +302,22 @@ struct ExitArgs {
   int conv_first, scale_by_t;
   WrapCoef w; const float2* xt; long long xt_bs;
   float2* out; int FT;
+  Rag rag; int F;            // ragged launch: FT_b = F * rag.w[b]; h4 / out at rag.off[b]; xt at rag.off[b] * xt_bs
 };
 
 __global__ __launch_bounds__(256) void exit_kernel(ExitArgs p) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.FT) return;
   const int b = blockIdx.y;
+  int FT = p.FT;
+  size_t po = (size_t)b * FT, xo = (size_t)b * p.xt_bs;
+  if (p.rag.w) { FT = p.F * p.rag.w[b]; po = (size_t)p.rag.off[b]; xo = po * p.xt_bs; }
+  if (i >= FT) return;
   const int step = p.step_ptr ? *p.step_ptr : 0;
   const float t = p.scale_by_t ? p.tvals[(size_t)step * p.t_sstride + (size_t)b * p.t_bstride] : 1.f;
-  const float* h = p.h4 + (size_t)b * 4 * p.FT + i;
+  const float* h = p.h4 + po * 4 + i;
   float hv[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) hv[c] = h[(size_t)c * p.FT];
+  for (int c = 0; c < 4; ++c) hv[c] = h[(size_t)c * FT];
   if (p.scale_by_t && !p.conv_first) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) hv[c] = hv[c] / t;
@@ -321,8 +334,8 @@ __global__ __launch_bounds__(256) void exit_kernel(ExitArgs p) {
   float g, al, be;
   wrap_coef(p.w, b, &g, &al, &be);
   float2 r = make_float2(be * o[0], be * o[1]);
-  if (al != 0.f) { const float2 xv = p.xt[(size_t)b * p.xt_bs + i]; r.x += al * xv.x; r.y += al * xv.y; }
-  p.out[(size_t)b * p.FT + i] = r;
+  if (al != 0.f) { const float2 xv = p.xt[xo + i]; r.x += al * xv.x; r.y += al * xv.y; }
+  p.out[po + i] = r;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -370,10 +383,16 @@ struct SamplerArgs {
   float snr; int B; int per;        // per = FT (elements per utterance)
   float* partial;                   // [B][LANG_NBLK][2] partial sums of |grad|^2, |z|^2
   float* lang;                      // [2]: step_size, sqrt(2*step_size)
+  const long long* rag_off; // ragged batch: [B + 1] element prefix of the packed utterances (null: B utterances of `per` elements)
 };
 
 __device__ __forceinline__ float2 sampler_noise(const SamplerArgs& p, int i, int draw) {
   if (p.noise) return p.noise[(size_t)draw * p.n + i];
+  if (p.rag_off) {            // the utterance this element belongs to: last b with rag_off[b] <= i
+    int lo = 0, hi = p.B;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.rag_off[mid] <= (long long)i) lo = mid; else hi = mid; }
+    return philox_cnormal(p.seed[0], (unsigned long long)((long long)i - p.rag_off[lo]), (uint32_t)draw, (uint32_t)p.seed[1 + lo]);
+  }
   const int b = i / p.per;
   return philox_cnormal(p.seed[0], (unsigned long long)(i - b * p.per), (uint32_t)draw, (uint32_t)p.seed[1 + b]);
 }

@@ -29,6 +29,11 @@
 
 namespace sgmse {
 
+// Per-utterance geometry of one U-Net level in a ragged launch (see ConvArgs::rag_w): w[b] = width of utterance b, off[b] = its
+// first pixel in the packed plane sets (sum over the utterances before it of H * w), soff[b] = the same prefix over its GroupNorm
+// statistics sub-tiles (H * ceil(w / 32)).  w == nullptr: every utterance has the launch's W (uniform batch).
+struct Rag { const int* w; const long long* off; const long long* soff; };
+
 struct ConvArgs {
   const float* src1; const float* src2;  // NCHW; virtual concat [src1 | src2] along C (src2 may be null)
   int C1, C2;
@@ -82,11 +87,44 @@ struct ConvArgs {
   // epilogue) by conv_splitk_reduce_kernel: bit-identical results, but the chunks run on different CUs (small batches).
   int kchunk_stages;
   float* partial;
+  // Ragged batches (utterances of different widths T_b in ONE launch, sgmse_set_frames): every tensor holds utterance b's planes
+  // with ITS OWN row stride W_b, packed one utterance after the other ([sum_b C*H*W_b] floats).  rag_w[b] = W_b of this launch's
+  // U-Net level, rag_off[b] = sum_{b' < b} H*W_b' (pixels of one channel plane set); W is then the widest utterance (the grid is
+  // laid out for it, tiles beyond W_b exit) and rag_slab the elements of one split-K partial slab.  conv_ragged_adjust() rewrites
+  // a workgroup's argument copy so that the uniform-batch addressing (b*C + c)*H*W lands on utterance b's block: what an
+  // utterance computes is exactly what its single-utterance launch computes, bit for bit.
+  const int* rag_w; const long long* rag_off; const long long* rag_soff; long long rag_slab;
+  int rag_vec_ok;             // ragged: every utterance's width is a multiple of 4 (float4 staging allowed)
   // measurement (ABL bit 6 instantiation): per workgroup {hw_id | xcc_id << 32, t_start, t_loop, t_epilogue, t_end} (shader clock)
   unsigned long long* trace;
 };
 
 constexpr int kAmaxSpread = 64;
+
+// ragged launch (ConvArgs::rag_w): point this workgroup's argument copy at utterance b; false = the tile lies beyond its width
+__device__ __forceinline__ bool conv_ragged_adjust(ConvArgs& p, int b, int tx) {
+  const int Wb = p.rag_w[b];
+  if (tx * 32 >= Wb) return false;
+  const long long d = p.rag_off[b] - (long long)b * p.H * Wb;
+  p.W = Wb;
+  p.src1 += d * p.C1;
+  if (p.src2) p.src2 += d * p.C2;
+  p.out += d * p.Cout;
+  if (p.res) p.res += d * p.Cout;
+  if (p.sc_src1) p.sc_src1 += d * p.sc_C1;
+  if (p.sc_src2) p.sc_src2 += d * p.sc_C2;
+  if (p.partial) p.partial += d * p.Cout;
+  if (p.stats_out) {            // statistics sub-tiles packed per utterance too: [soff[b] .. ) x Cout pairs, H * ceil(W_b / 32) per channel
+    const int nsub = p.H * ((Wb + 31) >> 5);
+    p.stats_out += (p.rag_soff[b] - (long long)b * nsub) * p.Cout * 2;
+    p.stats_nsub = nsub;
+  }
+  return true;
+}
+// elements between the split-K partial slabs of consecutive chunks
+__device__ __forceinline__ size_t conv_partial_slab(const ConvArgs& p, int H, int W) {
+  return p.rag_w ? (size_t)p.rag_slab : (size_t)p.B * p.Cout * H * W;
+}
 
 // max over the kAmaxSpread words of utterance b (every lane of the calling wave gets the result)
 __device__ __forceinline__ float amax_read(const float* amax, int b) {
@@ -328,12 +366,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
 
   const int tid = threadIdx.x;
   const int Cin = p.C1 + p.C2;
-  const int tiles_x = (p.W + 31) >> 5;
+  const int tiles_xg = (p.W + 31) >> 5;       // grid layout (ragged launches: of the widest utterance)
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
   int bid = blockIdx.x;
-  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
+  const int tiles_x = (p.W + 31) >> 5;
   const int x0 = tx * 32, y0 = ty * ROWS;
   const int co_blk = blockIdx.y;
   const int H = p.H, W = p.W;
@@ -582,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     }
     if (splitk) {                                      // raw partial sums of this chunk; the reduce kernel runs the epilogue
       ConvArgs q = p;
-      q.out = p.partial + (size_t)blockIdx.z * p.B * p.Cout * H * W;
+      q.out = p.partial + (size_t)blockIdx.z * conv_partial_slab(p, H, W);
       q.bias = nullptr; q.bias2 = nullptr; q.res = nullptr; q.acc_scale = nullptr; q.out_scale = 1.f; q.stats_out = nullptr; q.amax_out = nullptr;
       conv_epilogue<T, FC, FP, WC>(q, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
       return;
@@ -610,17 +650,19 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
   using T = ConvTile<KS, WC, FC, FP, 1>;
   constexpr int ROWS = T::ROWS, CO_T = T::CO_T;
   const int tid = threadIdx.x;
-  const int H = p.H, W = p.W;
-  const int tiles_x = (W + 31) >> 5;
-  const int tiles_y = (H + ROWS - 1) / ROWS;
+  const int tiles_xg = (p.W + 31) >> 5;
+  const int tiles_y = (p.H + ROWS - 1) / ROWS;
   int bid = blockIdx.x;
-  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
+  const int H = p.H, W = p.W;
+  const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
   const int wc = wave % WC, wp = wave / WC;
-  const size_t slab = (size_t)p.B * p.Cout * H * W;
+  const size_t slab = conv_partial_slab(p, H, W);
   const int x = tx * 32 + l31;
   f32x16 acc[FC][FP];
   // chunk loop OUTSIDE: the FC*FP*16 loads of one chunk are independent and in flight together; an element still sums its
@@ -668,10 +710,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
 template <int KS, int CG>
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs p) {
   constexpr int TAPS = KS * KS, HALO = KS / 2;
+  const int b = blockIdx.z;
+  if (p.rag_w) conv_ragged_adjust(p, b, 0);      // blocks past the utterance's pixels find inb == false below
   const int H = p.H, W = p.W, HW = H * W;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   const int co0 = blockIdx.y * CG;
-  const int b = blockIdx.z;
   const int Cin = p.C1 + p.C2;
   const bool inb = pix < HW;
   const int y = inb ? pix / W : 0, x = inb ? pix - (pix / W) * W : 0;

@@ -32,13 +32,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs p) {
 
   const int tid = threadIdx.x;
   const int Cin = p.C1 + p.C2;
-  const int H = p.H, W = p.W;
-  const int tiles_x = (W + 31) >> 5;
-  const int tiles_y = (H + T::ROWS - 1) / T::ROWS;
+  const int tiles_xg = (p.W + 31) >> 5;       // grid layout (ragged launches: of the widest utterance)
+  const int tiles_y = (p.H + T::ROWS - 1) / T::ROWS;
   int bid = blockIdx.x;
-  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
+  const int H = p.H, W = p.W;
+  const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
   const bool xform = p.in_scale != nullptr;
   for (int c = tid; c < Cin; c += 256) {

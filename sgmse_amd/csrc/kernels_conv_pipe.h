@@ -36,12 +36,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs p) {
 
   const int tid = threadIdx.x;
   const int Cin = p.C1 + p.C2;
-  const int tiles_x = (p.W + 31) >> 5;
+  const int tiles_xg = (p.W + 31) >> 5;       // grid layout (ragged launches: of the widest utterance)
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
   int bid = blockIdx.x;
-  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
+  const int tiles_x = (p.W + 31) >> 5;
   const int x0 = tx * 32, y0 = ty * ROWS;
   const int co_blk = blockIdx.y;
   const int H = p.H, W = p.W;

@@ -252,13 +252,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     }
   }
   const int Cin = p.C1 + p.C2;
-  const int H = p.H, W = p.W;
-  const int tiles_x = (W + 31) >> 5;
-  const int tiles_y = (H + ROWS - 1) / ROWS;
+  const int tiles_xg = (p.W + 31) >> 5;       // grid layout (ragged launches: of the widest utterance)
+  const int tiles_y = (p.H + ROWS - 1) / ROWS;
   int bid = blockIdx.x;
-  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
+  const int H = p.H, W = p.W;
+  const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
   const int x0 = tx * 32, y0 = ty * ROWS;
   {
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
         for (int j = 0; j < FPW; ++j) acc[i][j] = tot[i][j];
     } else {                                        // raw partial sums of this chunk; the reduce kernel runs the epilogue
       ConvArgs q = p;
-      q.out = p.partial + (size_t)blockIdx.z * p.B * p.Cout * H * W;
+      q.out = p.partial + (size_t)blockIdx.z * conv_partial_slab(p, H, W);
       q.bias = nullptr; q.bias2 = nullptr; q.res = nullptr; q.acc_scale = nullptr; q.out_scale = 1.f; q.stats_out = nullptr; q.amax_out = nullptr;
       conv_epilogue<T, FCW, FPW, WCW, 0, true>(q, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg);
       return;
@@ -634,13 +636,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
 
   const int tid = threadIdx.x;
   const int Cin = p.C1 + p.C2;
-  const int H = p.H, W = p.W;
-  const int tiles_x = (W + 31) >> 5;
-  const int tiles_y = (H + 7) >> 3;
+  const int tiles_xg = (p.W + 31) >> 5;       // grid layout (ragged launches: of the widest utterance)
+  const int tiles_y = (p.H + 7) >> 3;
   int bid = blockIdx.x;
-  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
+  const int H = p.H, W = p.W;
+  const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
   const int x0 = tx * 32, y0 = ty * 8;
   const bool xform = p.in_scale != nullptr;

@@ -22,13 +22,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // grid = B*C blocks of 256 threads; stats[(b*C+c)*2 + {0,1}] = {sum, sumsq}
+// ragged launch (rag.w): HW of utterance b = H * rag.w[b], its planes at rag.off[b] * C
 __global__ __launch_bounds__(256) void gn_chan_stats_kernel(const float* src1, const float* src2, int C1, int C2, int HW,
-                                                            float* stats) {
+                                                            float* stats, Rag rag, int H) {
   __shared__ float s_a[4];
   __shared__ float s_b[4];
   const int C = C1 + C2;
   const int b = blockIdx.x / C, c = blockIdx.x % C;
-  const float* plane = (c < C1) ? src1 + (size_t)(b * C1 + c) * HW : src2 + (size_t)(b * C2 + (c - C1)) * HW;
+  size_t pix0 = (size_t)b * HW;
+  if (rag.w) { HW = H * rag.w[b]; pix0 = (size_t)rag.off[b]; }
+  const float* plane = (c < C1) ? src1 + pix0 * C1 + (size_t)c * HW : src2 + pix0 * C2 + (size_t)(c - C1) * HW;
   float s = 0.f, q = 0.f;
   if ((HW & 3) == 0) {
     const float4* p4 = reinterpret_cast<const float4*>(plane);
@@ -71,22 +74,32 @@ __device__ __forceinline__ void gn_sum_pairs(const float* base, int n, double& s
 // grid = (G, B): one workgroup per group.  The partials of a group's channels are contiguous per source, so the 256 threads
 // stream them coalesced (fixed thread -> element map and a fixed fp64 tree: deterministic), then thread c < cpg writes the
 // folded coefficients of channel g*cpg + c.
+// Ragged launch (rag.w): utterance b has H * rag.w[b] pixels per plane; a source whose partials come from a convolution
+// epilogue (nsub > 1) holds them packed per utterance -- H * ceil(w / 32) sub-tiles per channel from sub-tile rag.soff[b] on,
+// exactly the layout of the utterance's own launch; gn_chan_stats sources (nsub == 1) are one pair per (b, c) either way.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* st1, int C1, int nsub1, const float* st2, int C2, int nsub2,
                                                           const float* gamma, const float* beta, int G, int HW, float eps,
-                                                          float* scale, float* shift) {
+                                                          float* scale, float* shift, Rag rag, int H) {
   __shared__ double s_s[256];
   __shared__ double s_q[256];
   const int g = blockIdx.x, b = blockIdx.y, C = C1 + C2, cpg = C / G;
   const int c_lo = g * cpg, c_hi = c_lo + cpg;
+  size_t sb1 = (size_t)b * nsub1, sb2 = (size_t)b * nsub2;       // first sub-tile of utterance b, per channel-set
+  if (rag.w) {
+    const int w = rag.w[b], ns = H * ((w + 31) >> 5);
+    HW = H * w;
+    if (nsub1 > 1) { nsub1 = ns; sb1 = (size_t)rag.soff[b]; }
+    if (nsub2 > 1) { nsub2 = ns; sb2 = (size_t)rag.soff[b]; }
+  }
   double s = 0.0, q = 0.0;
   // source 1 covers channels [c_lo, min(c_hi, C1)), source 2 the rest (a group may straddle the concat boundary)
   const int a_hi = c_hi < C1 ? c_hi : C1;
   if (c_lo < a_hi) {
-    gn_sum_pairs(st1 + ((size_t)b * C1 + c_lo) * nsub1 * 2, (a_hi - c_lo) * nsub1, s, q);
+    gn_sum_pairs(st1 + (sb1 * C1 + (size_t)c_lo * nsub1) * 2, (a_hi - c_lo) * nsub1, s, q);
   }
   const int b_lo = c_lo > C1 ? c_lo : C1;
   if (b_lo < c_hi) {
-    gn_sum_pairs(st2 + ((size_t)b * C2 + (b_lo - C1)) * nsub2 * 2, (c_hi - b_lo) * nsub2, s, q);
+    gn_sum_pairs(st2 + (sb2 * C2 + (size_t)(b_lo - C1) * nsub2) * 2, (c_hi - b_lo) * nsub2, s, q);
   }
   s_s[threadIdx.x] = s; s_q[threadIdx.x] = q;
   __syncthreads();
@@ -133,7 +146,22 @@ struct FirArgs {
   int BC, H, W;    // input plane geometry
   float* out_raw;  // optional second result FIR(x) of the same input (the ResBlock shortcut branch, layerspp.py:247-248,
                    // 254-255 resamples both h = act(GN(x)) and x): one pass over x feeds both
+  int C;           // channels per utterance (BC = B * C)
+  Rag rag;         // ragged launch: geometry of the INPUT level (the output level's prefix is off / 4 or off * 4); W = widest utterance
 };
+
+// ragged launch: point this workgroup's argument copy at the utterance of plane bc (same construction as conv_ragged_adjust:
+// the uniform addressing bc * H * W then lands on the utterance's own block with its own row stride)
+__device__ __forceinline__ void fir_ragged_adjust(FirArgs& p, int bc, bool up) {
+  const int b = bc / p.C;
+  const int Wb = p.rag.w[b];
+  const long long d = p.rag.off[b] - (long long)b * p.H * Wb;
+  p.W = Wb;
+  p.src += d * p.C;
+  const long long dout = up ? d * 4 : d / 4;
+  p.out += dout * p.C;
+  if (p.out_raw) p.out_raw += dout * p.C;
+}
 
 // raw value (0 outside the image) and, through *xv, its fused-producer image (also 0 outside)
 __device__ __forceinline__ float fir_fetch(const FirArgs& p, const float* plane, int y, int x, float a, float s, float* xv) {
@@ -147,10 +175,11 @@ __device__ __forceinline__ float fir_fetch(const FirArgs& p, const float* plane,
 
 // FIR /2: out[i][j] = sum_{a,b} k[a]k[b] x[2i+a-1][2j+b-1], k=[1,3,3,1]/8.  grid = (ceil(Ho*Wo/256), BC)
 __global__ __launch_bounds__(256) void fir_down2_kernel(FirArgs p) {
+  const int bc = blockIdx.y;
+  if (p.rag.w) fir_ragged_adjust(p, bc, false);
   const int Ho = p.H / 2, Wo = p.W / 2;
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= Ho * Wo) return;
-  const int bc = blockIdx.y;
   const int i = o / Wo, j = o - i * Wo;
   const float* plane = p.src + (size_t)bc * p.H * p.W;
   float a = 1.f, s = 0.f;
@@ -188,10 +217,11 @@ __device__ __forceinline__ void fir_up2_emit(const float (&v)[3][3], float* out,
 }
 
 __global__ __launch_bounds__(256) void fir_up2_kernel(FirArgs p) {
+  const int bc = blockIdx.y;
+  if (p.rag.w) fir_ragged_adjust(p, bc, true);
   const int H = p.H, W = p.W;
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= H * W) return;
-  const int bc = blockIdx.y;
   const int i = o / W, j = o - i * W;
   const float* plane = p.src + (size_t)bc * H * W;
   float a = 1.f, s = 0.f;
@@ -270,10 +300,11 @@ __global__ __launch_bounds__(256) void fir_down2_tiled_kernel(FirArgs p) {
   using TT = FirTileDown;
   __shared__ float sx[TT::IR * TT::RS];
   __shared__ float sr[TT::IR * TT::RS];
-  const int Ho = p.H / 2, Wo = p.W / 2;
-  const int tiles_x = (Wo + TT::TO_W - 1) / TT::TO_W;
+  const int tiles_x = (p.W / 2 + TT::TO_W - 1) / TT::TO_W;          // grid layout (ragged launches: of the widest utterance)
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int bc = blockIdx.y;
+  if (p.rag.w) { fir_ragged_adjust(p, bc, false); if (tx * TT::TO_W >= p.W / 2) return; }
+  const int Ho = p.H / 2, Wo = p.W / 2;
   const float* plane = p.src + (size_t)bc * p.H * p.W;
   float a = 1.f, s = 0.f;
   if (p.in_scale) { a = p.in_scale[bc]; s = p.in_shift[bc]; }
@@ -314,10 +345,11 @@ __global__ __launch_bounds__(256) void fir_up2_tiled_kernel(FirArgs p) {
   using TT = FirTileUp;
   __shared__ float sx[TT::IR * TT::RS];
   __shared__ float sr[TT::IR * TT::RS];
-  const int H = p.H, W = p.W;
-  const int tiles_x = (W + TT::TI_W - 1) / TT::TI_W;
+  const int tiles_x = (p.W + TT::TI_W - 1) / TT::TI_W;              // grid layout (ragged launches: of the widest utterance)
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int bc = blockIdx.y;
+  if (p.rag.w) { fir_ragged_adjust(p, bc, true); if (tx * TT::TI_W >= p.W) return; }
+  const int H = p.H, W = p.W;
   const float* plane = p.src + (size_t)bc * H * W;
   float a = 1.f, s = 0.f;
   if (p.in_scale) { a = p.in_scale[bc]; s = p.in_shift[bc]; }

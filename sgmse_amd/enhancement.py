@@ -10,6 +10,9 @@ Differences from the reference script, none of them in the arithmetic of one utt
   interact -- the network and sampler arithmetic of an utterance is bit-identical in any batch
   (``test_full_size_batch_independence``), only its noise draws depend on its slot -- whereas the reference loops over files
   one by one (``enhancement.py:57``);
+* with ``--ragged`` files of DIFFERENT padded lengths share a batch too (``sgmse_set_frames``: every kernel addresses an
+  utterance's block with the utterance's own row stride, so its arithmetic is still that of its single-file run, bit for bit):
+  the files of a shard are sorted by length and cut into batches of ``--batch_size`` whatever their lengths;
 * under ``torchrun`` every rank takes a contiguous shard of the sorted file list (the split of the reference's validation
   loop, ``model.py:212-223``), rank 0 reads the checkpoint and the weights reach the other ranks in one RCCL broadcast; there
   is no collective on the data path;
@@ -125,23 +128,36 @@ def enhance_files(model: ScoreModel, files: List[str], test_dir: str, enhanced_d
         frames = len(y) // hop + 1
         by_frames.setdefault((frames + 63) // 64 * 64, []).append(path)
     index = {path: first_index + k for k, path in enumerate(files)}
+    ragged = bool(getattr(args, "ragged", False))
+    if ragged and (model.sde.__class__.__name__ != "OUVESDE" or args.corrector == "langevin"):
+        import warnings
+        warnings.warn("--ragged needs an OUVE model and the 'ald' / 'none' corrector (the Langevin corrector couples the utterances of "
+                      "a batch; the Schroedinger-bridge sampler is not built for it): batching by padded length instead")
+        ragged = False
+    if ragged:
+        # one work list, shortest first (neighbours in a batch have similar lengths: few idle tiles), batches of any mix of lengths
+        order = sorted(files, key=lambda p: (lengths[p], p))
+        batches = [order[i:i + args.batch_size] for i in range(0, len(order), args.batch_size)]
+    else:
+        batches = [paths[i:i + args.batch_size] for _, paths in sorted(by_frames.items()) for i in range(0, len(paths), args.batch_size)]
     done = 0
-    for t_pad, paths in sorted(by_frames.items()):
-        for i in range(0, len(paths), args.batch_size):
-            chunk = paths[i:i + args.batch_size]
-            specs, peaks = [], []
-            for path in chunk:
-                y, peak = _load_normalised(path, target_sr)
-                Y = model._forward_transform(model._stft(y[None].to(device))).unsqueeze(1)      # [1,1,F,frames]
-                specs.append(pad_spec(Y, mode=pad_mode))
-                peaks.append(peak)
-            sample, _ = build_sampler(model, torch.cat(specs), args, args.seed, [index[p] for p in chunk])()
-            for j, path in enumerate(chunk):
-                x = model.to_audio(sample[j:j + 1, 0], lengths[path])[0].cpu().numpy()          # spec_back + iSTFT (enhancement.py:99)
-                name = path.replace(test_dir, "")
-                name = name[1:] if name.startswith("/") else name
-                write_audio(join(enhanced_dir, name), x * peaks[j], target_sr)                  # renormalise (enhancement.py:102)
-                done += 1
+    for chunk in batches:
+        specs, peaks = [], []
+        for path in chunk:
+            y, peak = _load_normalised(path, target_sr)
+            Y = model._forward_transform(model._stft(y[None].to(device))).unsqueeze(1)      # [1,1,F,frames]
+            specs.append(pad_spec(Y, mode=pad_mode))
+            peaks.append(peak)
+        uniform = len({int(Y.shape[-1]) for Y in specs}) == 1
+        Ys = torch.cat(specs) if uniform else [Y[0] for Y in specs]                         # ragged: list of [1,F,T_b]
+        sample, _ = build_sampler(model, Ys, args, args.seed, [index[p] for p in chunk])()
+        for j, path in enumerate(chunk):
+            spec = sample[j:j + 1, 0] if uniform else sample[j]
+            x = model.to_audio(spec, lengths[path])[0].cpu().numpy()                        # spec_back + iSTFT (enhancement.py:99)
+            name = path.replace(test_dir, "")
+            name = name[1:] if name.startswith("/") else name
+            write_audio(join(enhanced_dir, name), x * peaks[j], target_sr)                  # renormalise (enhancement.py:102)
+            done += 1
     return done
 
 
@@ -184,6 +200,7 @@ def main(argv=None) -> int:
     parser.add_argument("--t_eps", type=float, default=0.03, help="The minimum process time (0.03 by default)")
     parser.add_argument("--batch_size", type=int, default=32, help="Utterances of equal padded length enhanced together")
     parser.add_argument("--seed", type=int, default=None, help="Base seed of the sampler noise (default: unseeded, like the reference)")
+    parser.add_argument("--ragged", action="store_true", help="Batch files of different padded lengths together (OUVE models, pc / ode samplers, ald / none correctors)")
     args = parser.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))

@@ -32,7 +32,14 @@ def _native_engine(score_fn, y):
         return None
     if getattr(score_fn, "_native_score_wrapper", False) is not True:
         return None
-    return dnn.engine(y.device)
+    return dnn.engine(y[0].device if isinstance(y, (list, tuple)) else y.device)
+
+
+def _require_native_for_ragged(ctx, y):
+    """A list of spectrograms of different lengths (ragged batch, Context.set_frames) only runs on the native samplers."""
+    if ctx is None and isinstance(y, (list, tuple)):
+        raise TypeError("a list of spectrograms (ragged batch) needs the native HIP sampler: OUVESDE, 'reverse_diffusion'/'none' "
+                        "predictor, 'ald'/'none' corrector, no force_python_loop")
 
 
 def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=True, eps=3e-2, snr=0.1, corrector_steps=1,
@@ -51,6 +58,7 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=Tru
     native = (not force_python_loop and predictor_name in _NATIVE_PRED and corrector_name in _NATIVE_CORR
               and isinstance(sde, OUVESDE) and not intermediate)
     ctx = _native_engine(score_fn, y) if native else None
+    _require_native_for_ragged(ctx, y)
 
     if ctx is not None:
         table = sde.step_table(eps, snr, sde.N)
@@ -104,6 +112,7 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
         warnings.warn(f"get_ode_sampler: {', '.join(ignored)} ignored -- this is the fixed-step probability-flow Euler sampler (N steps, "
                       f"N NFE), not the reference's adaptive scipy solver; results are not comparable with a reference ODE run")
     ctx = _native_engine(score_fn, y) if isinstance(sde, OUVESDE) else None
+    _require_native_for_ragged(ctx, y)
     if ctx is None:
         rsde = sde.reverse(score_fn, probability_flow=True)
 

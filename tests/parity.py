@@ -528,7 +528,7 @@ def check_enhancement_script(dev, tmp_path, monkeypatch):
     noisy = tmp_path / "noisy"
     (noisy / "sub").mkdir(parents=True)
     rng = torch.Generator().manual_seed(5)
-    lengths = {"a.wav": 2000, "b.wav": 2000, "sub/c.wav": 2600}
+    lengths = {"a.wav": 2000, "b.wav": 2000, "sub/c.wav": 8500}      # 16, 16 and 67 frames: padded to 64, 64 and 128
     for name, L in lengths.items():
         wavfile.write(str(noisy / name), 16000, (0.1 * torch.randn(L, generator=rng)).numpy())
     base = ["--test_dir", str(noisy), "--ckpt", str(ckpt), "--device", str(dev), "--N", "1", "--seed", "7"]
@@ -540,6 +540,10 @@ def check_enhancement_script(dev, tmp_path, monkeypatch):
         _, x2 = wavfile.read(str(tmp_path / "o2" / name))
         assert sr == 16000 and x1.shape == (L,) and np.isfinite(x1).all() and np.abs(x1).max() > 0
         assert np.array_equal(x1, x2)        # noise = f(seed, index in the file list): the batch size does not matter
+    with pytest.warns(UserWarning):          # all three files in ONE ragged batch (frames 64, 64, 128): still the same samples
+        assert E.main(base + ["--enhanced_dir", str(tmp_path / "o4"), "--ragged", "--batch_size", "3"]) == 3
+    for name in lengths:
+        assert np.array_equal(wavfile.read(str(tmp_path / "o1" / name))[1], wavfile.read(str(tmp_path / "o4" / name))[1])
     monkeypatch.setenv("WORLD_SIZE", "2")
     monkeypatch.delenv("MASTER_PORT", raising=False)      # no rendezvous: every rank reads the checkpoint itself
     seen = 0
@@ -629,3 +633,43 @@ def check_poison_independence(dev, name="fwd_nf128", every_layer_split=False):
     assert torch.isfinite(torch.view_as_real(outs[1])).all()
     assert torch.equal(outs[0], outs[1])
     assert rel_l2(outs[1], torch.from_numpy(z["out"])) < NET_TOL
+
+
+def check_ragged_batch(dev, name="fwd_nf32", frames=(128, 64, 192), sampler=True, quick=False):
+    """Ragged batches (sgmse_set_frames): utterances of different frame counts in ONE launch, each with its own row stride in
+    every tensor.  Forward and samplers must give every utterance the bits of its single-utterance call -- the arithmetic of an
+    utterance does not depend on what else is in the batch, nor on its own length class (kernel families follow the U-Net
+    level only)."""
+    cfg = NET_CASES[name]
+    m, _ = make_model(cfg, dev)
+    eng = m.dnn.engine(torch.device(dev))
+    g = torch.Generator().manual_seed(3)
+    xs = [(torch.randn(2, 256, T, dtype=torch.complex64, generator=g) * 0.3).to(dev) for T in frames]
+    t = torch.tensor([0.9, 0.4, 0.1, 0.6, 0.25][:len(frames)], device=dev)
+    singles = [eng.forward(x[None], t[i:i + 1])[0] for i, x in enumerate(xs)]
+    for a, b in zip(singles, eng.forward_ragged(xs, t)):
+        assert a.shape == b.shape and torch.equal(a, b)
+    if not quick:
+        perm = list(range(len(frames)))[::-1]                  # any order, any neighbours
+        for a, b in zip([singles[i] for i in perm], eng.forward_ragged([xs[i] for i in perm], t[perm])):
+            assert torch.equal(a, b)
+    assert torch.equal(eng.forward(xs[-1][None], t[-1:])[0], singles[-1])   # and back to uniform batches
+    if not sampler:
+        return
+    ys = [synth.synth_spec(1, 256, T, seed=3 + i)[0].to(dev) for i, T in enumerate(frames)]
+    ids = [7 + i for i in range(len(frames))]
+    N = 1 if quick else 2
+    makers = [lambda y, st: m.get_pc_sampler("reverse_diffusion", "ald", y, N=N, snr=0.5, seed=5, streams=st),
+              lambda y, st: m.get_ode_sampler(y, N=N, seed=5, streams=st)]
+    if not quick:
+        makers.append(lambda y, st: m.get_pc_sampler("none", "ald", y, N=N, snr=0.5, seed=5, streams=st))
+    for make in makers:
+        one_by_one = [make(y[None], [ids[i]])()[0][0] for i, y in enumerate(ys)]
+        together, nfe = make(ys, ids)()
+        assert len(together) == len(ys) and nfe > 0
+        for a, b in zip(one_by_one, together):
+            assert a.shape == b.shape and torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="Langevin"):
+        m.get_pc_sampler("reverse_diffusion", "langevin", ys, N=1, snr=0.5, seed=5)()
+    with pytest.raises(TypeError):
+        m.get_pc_sampler("reverse_diffusion", "ald", ys, N=1, snr=0.5, seed=5, force_python_loop=True)

@@ -235,3 +235,12 @@ def test_reference_enhancement_script_runs_unmodified(emu, tmp_path, monkeypatch
 
 def test_results_do_not_depend_on_what_device_memory_held(emu):
     P.check_poison_independence(emu, "fwd_nf32")
+
+
+def test_ragged_batch_gives_every_utterance_its_single_run_bits(emu):
+    P.check_ragged_batch(emu, "fwd_nf32", frames=(128, 64), quick=True)
+
+
+@pytest.mark.skipif(not os.environ.get("SGMSE_SLOW"), reason="full-width network on the emulator: minutes (SGMSE_SLOW=1)")
+def test_ragged_batch_full_width(emu):
+    P.check_ragged_batch(emu, "fwd_nf128", frames=(128, 64), sampler=False)

@@ -438,6 +438,11 @@ def test_sampler_does_not_depend_on_what_device_memory_held(hip, monkeypatch):
     P.check_sampler_golden(hip, "pc_N4")
 
 
+def test_ragged_batch_gives_every_utterance_its_single_run_bits(hip):
+    """Full width, frame counts from 64 to 512 in one batch: forward, PC, corrector-free PC and PF-ODE samplers (captured graph)."""
+    P.check_ragged_batch(hip, "fwd_nf128", frames=(512, 64, 192, 320, 128))
+
+
 def test_enhancement_script_directory_to_directory(hip, tmp_path, monkeypatch):
     P.check_enhancement_script(hip, tmp_path, monkeypatch)
 
