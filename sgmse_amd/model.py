@@ -240,14 +240,17 @@ class ScoreModel(nn.Module):
     def _chunked(self, make_sampler, y, minibatch, kwargs):
         """``minibatch`` wrapper of reference model.py:356-368 / 378-390: the batch in serial chunks, samples concatenated and
         the chunks' nfe collected in a list."""
+        ragged = isinstance(y, (list, tuple))         # a list of spectrograms of different lengths (Context.set_frames)
+        total = len(y) if ragged else y.shape[0]
+
         def batched_sampling_fn():
             samples, ns = [], []
-            for lo in range(0, y.shape[0], minibatch):
-                hi = min(lo + minibatch, y.shape[0])
+            for lo in range(0, total, minibatch):
+                hi = min(lo + minibatch, total)
                 sample, n = make_sampler(y[lo:hi], self._minibatch_kwargs(kwargs, lo, hi))()
                 samples.append(sample)
                 ns.append(n)
-            return torch.cat(samples, dim=0), ns
+            return ([s for chunk in samples for s in chunk] if ragged else torch.cat(samples, dim=0)), ns
         return batched_sampling_fn
 
     def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, **kwargs):

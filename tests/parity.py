@@ -673,3 +673,20 @@ def check_ragged_batch(dev, name="fwd_nf32", frames=(128, 64, 192), sampler=True
         m.get_pc_sampler("reverse_diffusion", "langevin", ys, N=1, snr=0.5, seed=5)()
     with pytest.raises(TypeError):
         m.get_pc_sampler("reverse_diffusion", "ald", ys, N=1, snr=0.5, seed=5, force_python_loop=True)
+
+
+def check_ragged_variants(dev):
+    """Ragged batches through the other two network variants: ncsnpp_v2 with the new-code score wrapper (the exit kernel reads
+    x_t of the packed sampler state) and ncsnpp_48k (no pyramids, final convolution), on a 64-bin network."""
+    frames = [128, 64]
+    for cfg, wrap in ((NO.NetCfg.for_variant("ncsnpp_v2", nf=32, image_size=64),
+                       dict(loss_type="denoiser", network_scaling="1/t", c_in="edm", c_out="edm", c_skip="edm", sigma_data=0.1)),
+                      (NO.NetCfg.for_variant("ncsnpp_48k", nf=32, image_size=64), {})):
+        m, _ = make_model(cfg, dev, **wrap)
+        ys = [synth.synth_spec(1, 64, T, seed=3 + i)[0].to(dev) for i, T in enumerate(frames)]
+        one = [m.get_pc_sampler("reverse_diffusion", "ald", y[None], N=1, snr=0.5, seed=5, streams=[4 + i])()[0][0] for i, y in enumerate(ys)]
+        together, _ = m.get_pc_sampler("reverse_diffusion", "ald", ys, N=1, snr=0.5, seed=5, streams=[4, 5])()
+        chunked, ns = m.get_pc_sampler("reverse_diffusion", "ald", ys, N=1, snr=0.5, seed=5, streams=[4, 5], minibatch=1)()
+        assert ns == [2, 2]
+        for a, b, c in zip(one, together, chunked):
+            assert torch.equal(a, b) and torch.equal(a, c)

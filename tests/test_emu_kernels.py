@@ -244,3 +244,7 @@ def test_ragged_batch_gives_every_utterance_its_single_run_bits(emu):
 @pytest.mark.skipif(not os.environ.get("SGMSE_SLOW"), reason="full-width network on the emulator: minutes (SGMSE_SLOW=1)")
 def test_ragged_batch_full_width(emu):
     P.check_ragged_batch(emu, "fwd_nf128", frames=(128, 64), sampler=False)
+
+
+def test_ragged_batch_other_variants_and_minibatch(emu):
+    P.check_ragged_variants(emu)
