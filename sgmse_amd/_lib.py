@@ -155,6 +155,7 @@ class Context:
             raise SgmseLibraryError(f"sgmse_ctx_create failed ({rc})")
         self.h = h
         self._keep: Dict[str, object] = {}
+        self._frames: list = []          # frame table in force in the library (set_frames); [] = uniform batches
 
     def __del__(self):
         try:
@@ -242,6 +243,7 @@ class Context:
         if t.numel() != B:
             raise ValueError("time_cond must have one entry per batch element")
         out = torch.empty((B, 1, F_, T), dtype=torch.complex64, device=self.device)
+        self.set_frames([])
         self.use_current_stream()
         self.check(self.lib.sgmse_ncsnpp_forward(self.h, xy.data_ptr(), t.data_ptr(), out.data_ptr(), B, F_, T))
         return out
@@ -297,14 +299,11 @@ class Context:
 
         def run():
             self.use_current_stream()
-            if frames is not None:
-                self.set_frames(frames)
-            try:
-                self.check(self.lib.sgmse_pc_sample(self.h, Y.data_ptr(), out.data_ptr(), B, F_, T, C.byref(cfg), ptr(noise),
-                                                    C.c_ulonglong(seed & (2 ** 64 - 1)), C.byref(nfe)))
-            finally:
-                if frames is not None:
-                    self.set_frames([])
+            # the frame table stays in force between calls: consecutive ragged batches of one composition re-use the arena plan
+            # and the captured graph; a uniform call switches it off
+            self.set_frames(frames if frames is not None else [])
+            self.check(self.lib.sgmse_pc_sample(self.h, Y.data_ptr(), out.data_ptr(), B, F_, T, C.byref(cfg), ptr(noise),
+                                                C.c_ulonglong(seed & (2 ** 64 - 1)), C.byref(nfe)))
 
         cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         if cur is not None and use_graph and cur.cuda_stream == 0:
@@ -351,6 +350,7 @@ class Context:
 
         def run():
             self.use_current_stream()
+            self.set_frames([])
             self.check(self.lib.sgmse_sb_sample(self.h, Y.data_ptr(), out.data_ptr(), B, F_, T, N, *[fp(v) for v in keep],
                                                 *[None if v is None else fp(v) for v in aff], int(bool(stochastic)), ptr(noise),
                                                 C.c_ulonglong(seed & (2 ** 64 - 1)), int(bool(use_graph)), C.byref(nfe)))
@@ -378,6 +378,7 @@ class Context:
         fl = (C.c_double * SGMSE_NCLASS)()
         nl = (_I * SGMSE_NCLASS)()
         self.use_current_stream()
+        self.set_frames([])
         self.check(self.lib.sgmse_profile_forward(self.h, xy.data_ptr(), t.data_ptr(), out.data_ptr(), B, F_, T, ms, fl, nl))
         return {n: {"ms": ms[i], "work": fl[i], "unit": CLASS_WORK_UNIT[i], "launches": nl[i]}
                 for i, n in enumerate(CLASS_NAMES)}, out
@@ -403,8 +404,11 @@ class Context:
     def set_frames(self, frames) -> None:
         """Ragged batches (sgmse_set_frames): frame count of every utterance of the following calls; [] = uniform batches again."""
         frames = [int(v) for v in frames]
+        if frames == self._frames:            # unchanged: the library keeps its tables, arena plan and captured graph
+            return
         arr = (_I * max(len(frames), 1))(*frames)
         self.check(self.lib.sgmse_set_frames(self.h, arr if frames else None, len(frames)))
+        self._frames = frames
 
     def forward_ragged(self, xys, t: torch.Tensor):
         """NCSNpp.forward on utterances of different lengths in ONE batch: xys = list of complex64 [2,F,T_b]; returns the list of
@@ -417,11 +421,8 @@ class Context:
             raise ValueError("time_cond must have one entry per utterance")
         out = torch.empty(F_ * sum(frames), dtype=torch.complex64, device=self.device)
         self.set_frames(frames)
-        try:
-            self.use_current_stream()
-            self.check(self.lib.sgmse_ncsnpp_forward(self.h, packed.data_ptr(), t.data_ptr(), out.data_ptr(), len(xys), F_, max(frames)))
-        finally:
-            self.set_frames([])
+        self.use_current_stream()
+        self.check(self.lib.sgmse_ncsnpp_forward(self.h, packed.data_ptr(), t.data_ptr(), out.data_ptr(), len(xys), F_, max(frames)))
         outs, o = [], 0
         for T_b in frames:
             outs.append(out[o:o + F_ * T_b].reshape(1, F_, T_b))
