@@ -329,9 +329,28 @@ class ScoreModel(nn.Module):
 
     def enhance_batch(self, y, N=30, corrector="ald", corrector_steps=1, snr=0.5, pad_mode="zero_pad", noise=None, seed=None,
                       predictor="reverse_diffusion", sampler_type="pc", use_graph=True, streams=None):
-        """Batched form of enhancement.py:62-99 for B utterances of equal length: y float32 [B, L] on the model's device
-        -> enhanced float32 [B, L] (stays on the device).  Not in the reference (which loops files one by one)."""
+        """Batched form of enhancement.py:62-99: y float32 [B, L] (B utterances of equal length) -> enhanced float32 [B, L] on the
+        model's device; or a LIST of 1-D waveforms of different lengths -> list of enhanced waveforms (one ragged batch, each
+        utterance bit-identical to its own single call with the same seed and stream id).  Not in the reference (which loops
+        files one by one)."""
         dev = self._device()
+        if isinstance(y, (list, tuple)):
+            # utterances of DIFFERENT lengths: one ragged batch (Context.set_frames) -- every utterance through its own STFT and
+            # pad_spec, sampled together, inverted with its own length; returns a list of 1-D waveforms
+            if noise is not None:
+                raise ValueError("a list of waveforms (ragged batch) uses in-kernel noise only")
+            ys = [w.reshape(1, -1).to(dev) for w in y]
+            norms = [w.abs().max() for w in ys]
+            Ys = [pad_spec(self._forward_transform(self._stft(w / n)).unsqueeze(1), mode=pad_mode)[0] for w, n in zip(ys, norms)]
+            if sampler_type == "pc":
+                sampler = self.get_pc_sampler(predictor, corrector, Ys, N=N, corrector_steps=corrector_steps, snr=snr, seed=seed,
+                                              use_graph=use_graph, streams=streams)
+            elif sampler_type == "ode":
+                sampler = self.get_ode_sampler(Ys, N=N, seed=seed, use_graph=use_graph, streams=streams)
+            else:
+                raise ValueError(f"Sampler type {sampler_type} not supported")
+            samples, nfe = sampler()
+            return [self.to_audio(s, w.size(1))[0] * n for s, w, n in zip(samples, ys, norms)], nfe
         y = y.to(dev)
         T_orig = y.size(1)
         norm = y.abs().amax(dim=1, keepdim=True)

@@ -690,3 +690,10 @@ def check_ragged_variants(dev):
         assert ns == [2, 2]
         for a, b, c in zip(one, together, chunked):
             assert torch.equal(a, b) and torch.equal(a, c)
+    # waveforms of different lengths through ScoreModel.enhance_batch (STFT, pad_spec, ragged sampler, iSTFT per utterance)
+    m, _ = make_model(NET_CASES["fwd_nf32"], dev)
+    g = torch.Generator().manual_seed(2)
+    waves = [torch.randn(L, generator=g) for L in (3000, 9000)]
+    alone = [m.enhance_batch(w[None], N=1, seed=4, streams=[5 + i])[0][0] for i, w in enumerate(waves)]
+    mixed, nfe = m.enhance_batch(waves, N=1, seed=4, streams=[5, 6])
+    assert nfe == 2 and all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(alone, mixed))
