@@ -1171,7 +1171,7 @@ class Engine {
 
   // residual shortcut folded into a 3x3 split launch (ConvArgs::sc_*): the 1x1 layer and its (raw) input
   struct Shortcut { const ConvW* w; const Tensor* a; const Tensor* b; };
-  // would conv() run this 3x3 layer (GroupNorm producer in front) on the fp16x2 split kernel at this image size?  (the rule below)
+  // would conv() run this 3x3 layer (GroupNorm producer in front) on the fp16x2 split kernel at this level?  (the rule below; W = dec_W)
   bool runs_on_h2_split3(const ConvW& w, int C, int H, int W) const {
     return w.packed && w.packed_split && w.split_mode == 2 && w.ks == 3 && w.cout > 32 && conv_split_eligible(3, C, 0, w.cout) &&
            (long)((H + 7) / 8) * ((W + 31) / 32) >= split_min_tiles_;
@@ -1205,14 +1205,14 @@ class Engine {
           if (nblk >= tile_min_blocks_) done = true;
         }
     }
-    // fp32-accurate bf16x3 kernel for the wide levels.  Decided per layer and per IMAGE (never by the batch size), because
+    // fp32-accurate bf16x3 kernel for the wide levels.  Decided per layer and per LEVEL (never by the batch size or the utterance length), because
     // its results differ from the fp32-MFMA kernels in the last bits and an utterance must not depend on its batch.
     const int Wd = dec_W(a.H);          // family decisions by the level, not by the utterance length (see dec_W)
     const long tiles8 = (long)((a.H + 7) / 8) * ((Wd + 31) / 32);
-    // Levels with 2..chunk_max_tiles_ tiles per image (16 x 32, 32 x 64): the fp16x2 split kernel in its 4-row shape with CHUNKED
+    // Levels with 2..chunk_max_tiles_ tiles per nominal image (16 x 32, 32 x 64): the fp16x2 split kernel in its 4-row shape with CHUNKED
     // accumulation, so that a small batch can spread the chunks over workgroups (split-K, bit-identical) instead of running 16-32
     // serial stages on 8-32 workgroups; full 3x3 blocks behind a GroupNorm producer only (not the launches with a folded
-    // shortcut).  Decided per layer and image size, never by the batch: chunking fixes the summation order.
+    // shortcut).  Decided per layer and level, never by the batch or the utterance length: chunking fixes the summation order.
     const bool coarse_split = coarse_split_ && use_mfma && w.packed_split && w.split_mode == 2 && w.ks == 3 && w.cout > 32 && !sc &&
                               conv_split_eligible(3, a.C, b ? b->C : 0, w.cout) && tiles8 >= chunk_min_tiles_ && tiles8 <= chunk_max_tiles_ &&
                               Wd >= chunk_min_width_ &&
@@ -1224,7 +1224,7 @@ class Engine {
                         // raw residual stream and scale by the producers' range bounds, which must then be known
                         (w.split_mode != 2 || (w.ks == 3 ? (xf.scale != nullptr || xf.bounded)
                                                          : (xf.scale == nullptr && a.amax && (!b || b->amax)))));
-    // Coarse levels (at most 512 pixels per image) on the fp32 kernels: 32-channel tiles with CHUNKED accumulation (decided per
+    // Coarse levels (at most 512 pixels per nominal image) on the fp32 kernels: 32-channel tiles with CHUNKED accumulation (decided per
     // layer and image, never by the batch: it fixes the summation order), and -- when even those tiles leave most CUs idle
     // (small batches) -- the chunks spread over workgroups (split-K, bit-identical): a K loop of 32-64 serial stages was the
     // latency of these launches (60-120 us each at batch 1, profiles/r02_prof_dump_b1_per_launch.txt)
