@@ -12,7 +12,8 @@ Differences from the reference script, none of them in the arithmetic of one utt
   one by one (``enhancement.py:57``);
 * with ``--ragged`` files of DIFFERENT padded lengths share a batch too (``sgmse_set_frames``: every kernel addresses an
   utterance's block with the utterance's own row stride, so its arithmetic is still that of its single-file run, bit for bit):
-  the files of a shard are sorted by length and cut into batches of ``--batch_size`` whatever their lengths;
+  full batches of one padded length still run as uniform batches, the leftovers of all lengths are pooled, sorted by length and
+  cut into ragged batches of ``--batch_size`` (a ragged batch costs 1.16 x a uniform one per frame, a small uniform batch more);
 * under ``torchrun`` every rank takes a contiguous shard of the sorted file list (the split of the reference's validation
   loop, ``model.py:212-223``), rank 0 reads the checkpoint and the weights reach the other ranks in one RCCL broadcast; there
   is no collective on the data path;
@@ -135,9 +136,15 @@ def enhance_files(model: ScoreModel, files: List[str], test_dir: str, enhanced_d
                       "a batch; the Schroedinger-bridge sampler is not built for it): batching by padded length instead")
         ragged = False
     if ragged:
-        # one work list, shortest first (neighbours in a batch have similar lengths: few idle tiles), batches of any mix of lengths
-        order = sorted(files, key=lambda p: (lengths[p], p))
-        batches = [order[i:i + args.batch_size] for i in range(0, len(order), args.batch_size)]
+        # full batches of one padded length run as uniform batches (the fastest form); what is left over of every length is pooled,
+        # shortest first (neighbours in a batch have similar lengths), and cut into ragged batches of any mix of lengths
+        batches, rest = [], []
+        for _, paths in sorted(by_frames.items()):
+            nfull = len(paths) // args.batch_size * args.batch_size
+            batches += [paths[i:i + args.batch_size] for i in range(0, nfull, args.batch_size)]
+            rest += paths[nfull:]
+        rest.sort(key=lambda p: (lengths[p], p))
+        batches += [rest[i:i + args.batch_size] for i in range(0, len(rest), args.batch_size)]
     else:
         batches = [paths[i:i + args.batch_size] for _, paths in sorted(by_frames.items()) for i in range(0, len(paths), args.batch_size)]
     done = 0
