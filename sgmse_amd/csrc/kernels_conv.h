@@ -63,6 +63,10 @@ struct ConvArgs {
   // per-utterance range bounds of src1 / src2 ([B][kAmaxSpread] each, from the producers' amax_out) for a consumer that
   // scales its input dynamically (conv1x1_split_kernel<SplitH2>); null otherwise
   const float* amax1; const float* amax2;
+  // per-utterance upper bound of |producer output| ([B][kAmaxSpread], written by gn_finalize_kernel from the utterance's own
+  // statistics and range bound) for the fp16x2 3x3 kernel: its input scale is the power of two that puts this bound in
+  // [2^13, 2^14) -- data-driven, per utterance, no presumption about GroupNorm parameters or utterance length
+  const float* xbound;
   // measurement-only ablation switches of the fp32 kernels for sgmse_bench_conv (results are then WRONG on purpose):
   // bit 2 stage only the first K-stage, bit 3 skip the barriers (the epilogue's switches are compile-time: conv_epilogue<ABL>)
   int ablate;
@@ -132,6 +136,15 @@ __device__ __forceinline__ float amax_read(const float* amax, int b) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   return m;
+}
+
+// exact power of two 2^k with m 2^k in [2^13, 2^14): the operand scale of the fp16x2 kernels for a tensor bounded by m
+__device__ __forceinline__ float h2_weight_scale(float absmax) {
+  if (!(absmax > 0.f)) return 1.f;
+  const int e = (int)((__builtin_bit_cast(uint32_t, absmax) >> 23) & 0xff) - 127;    // floor(log2(absmax)) for normals
+  int k = 13 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  return __builtin_bit_cast(float, (uint32_t)(k + 127) << 23);
 }
 
 // SiLU x*sigmoid(x) (nn.SiLU, reference layers.py:38-39) on the hardware exp2/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each,
@@ -702,7 +715,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
         if (!(co < p.Cout && y < H && x < W)) acc[i][j][r] = 0.f;
       }
     }
-  conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
+  // chunks of the fp16x2 kernel carry its per-utterance input scale (ConvArgs::xbound); the fp32 kernels' chunks carry none
+  float as_mul = 1.0f;
+  if (p.xbound) as_mul = 1.0f / h2_weight_scale(amax_read(p.xbound, b));
+  conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as_mul);
 }
 
 // Direct (VALU) convolution: one thread per output pixel, CG output channels per thread.

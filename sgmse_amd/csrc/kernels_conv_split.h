@@ -12,11 +12,15 @@
 //   SplitH2 ("fp16x2"): x * 2^s = hi + lo + e, hi = RN_f16(x 2^s), lo = RN_f16(x 2^s - hi), |e| <= 2^-24 |x 2^s| (two
 //     round-to-nearest 11-bit terms cover 22-23 bits plus the sign of lo).  a*b from hi*hi + hi*lo + lo*hi (lo*lo <=
 //     2^-24): relative error <= ~3 x 2^-24 per product, i.e. within one bit of fp32.  Three MFMAs: 5.3x the fp32 peak.
-//     fp16 has a narrow exponent range, so both operands are pre-scaled by exact powers of two: activations (always the
-//     output of the fused GroupNorm+SiLU producer here: O(1)) by 2^4 and saturated at +-65504 (|x| > 4094 cannot come
-//     out of a GroupNorm), the weights of a layer by 2^k with max|w| 2^k in [2^13, 2^14) (chosen by the packing kernel,
-//     which also stores 2^-(k+4) for the epilogue).  Small operands fall into fp16 subnormals; their ABSOLUTE error
-//     stays <= 2^-25 of the scaled unit, which is what matters for a sum.
+//     fp16 has a narrow exponent range, so both operands are pre-scaled by exact powers of two: the weights of a layer by
+//     2^k with max|w| 2^k in [2^13, 2^14) (chosen by the packing kernel, which also stores 2^-k for the epilogue), the
+//     activations -- always the output of the fused GroupNorm(+SiLU) producer here, or its FIR resampling -- PER UTTERANCE
+//     by the power of two that puts an upper bound of |producer output| in [2^13, 2^14).  The bound comes from the
+//     utterance's own data (gn_finalize_kernel: min(max|x| + |mean|, sqrt(N var)) rstd |gamma| + |beta| over the channels),
+//     so no GroupNorm parameter and no utterance length is presumed, and an utterance's scale does not depend on its batch.
+//     Small operands fall into fp16 subnormals; their ABSOLUTE error stays <= 2^-25 of the scaled unit, which is what
+//     matters for a sum (fp32-equivalent as long as the bound is within 2^14 of the typical magnitude; the sqrt(N var) term
+//     keeps it there when single channels or pixels are hot).
 //
 // Both are checked against an fp64 convolution next to the fp32-MFMA kernel (tests: check_conv_split) and pass the same
 // 1e-5 per-op / 2e-5 per-network parity gates as the fp32 kernels.
@@ -96,7 +100,6 @@ struct SplitH2 {
   }
   __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) { return mfma_32x32x16_f16(a, b, c); }
 };
-constexpr float kH2XScale = 16.f;
 
 template <int ROWS_>
 struct ConvSplitGeom {
@@ -106,9 +109,9 @@ struct ConvSplitGeom {
 };
 
 // Weight packing.  src: OIHW fp32 [Cout][Cin][k][k] (taps = k*k = 9 or 1); dst: u32x4 [nCoBlk][Cin/16][taps][NS][4][64], followed (SplitH2) by
-// one float: the factor 2^-(k+4) that takes the accumulator back to the unscaled convolution.  `absmax` (device,
+// one float: the factor 2^-k that undoes the weights' scale (the input's per-utterance scale is undone by the kernel).  `absmax` (device,
 // SplitH2 only) = max |w| of the layer, from absmax_kernel.  One thread per 16-byte fragment element.
-struct PackSplitArgs { const float* src; uint32_t* dst; int cin, cout; size_t total; const float* absmax; int taps; float xscale; };
+struct PackSplitArgs { const float* src; uint32_t* dst; int cin, cout; size_t total; const float* absmax; int taps; };
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t n, float* out) {   // *out zeroed by the caller
   float m = 0.f;
@@ -118,15 +121,6 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t n, f
   if ((threadIdx.x & 63) == 0) drt_atomic_max_nonneg(out, m);
 }
 
-// exact power of two 2^k with max|w| 2^k in [2^13, 2^14)
-__device__ __forceinline__ float h2_weight_scale(float absmax) {
-  if (!(absmax > 0.f)) return 1.f;
-  const int e = (int)((__builtin_bit_cast(uint32_t, absmax) >> 23) & 0xff) - 127;    // floor(log2(absmax)) for normals
-  int k = 13 - e;
-  k = k > 100 ? 100 : (k < -100 ? -100 : k);
-  return __builtin_bit_cast(float, (uint32_t)(k + 127) << 23);
-}
-
 template <class S>
 __global__ __launch_bounds__(256) void pack_weights_split_kernel(PackSplitArgs p) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -134,7 +128,7 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(PackSplitArgs p
   float wscale = 1.f;
   if (S::SCALED) {
     wscale = h2_weight_scale(*p.absmax);
-    if (e == 0) reinterpret_cast<float*>(p.dst)[p.total * 4] = 1.f / (wscale * p.xscale);   // xscale: the consumer's fixed input scale (1 if dynamic)
+    if (e == 0) reinterpret_cast<float*>(p.dst)[p.total * 4] = 1.f / wscale;   // the consumers' input scales are per utterance and undone by them
   }
   const int lane = (int)(e & 63);
   size_t r = e >> 6;
@@ -183,10 +177,10 @@ inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<
 //
 // Fused producer, per staged element (the VALU work of this kernel: it runs beside the MFMA stream and its instruction
 // count sets the power the matrix pipe is left with):
-//     t  = x * s + h            s, h: GroupNorm scale/shift of the channel, pre-multiplied by the fp16x2 input scale 2^4
-//     u  = x * s2 + h2          s2, h2 = -log2(e) * (s, h) / 2^4: the exponent of exp(-t) without a dependent multiply
+//     t  = x * s + h            s, h: GroupNorm scale/shift of the channel, pre-multiplied by the utterance's fp16x2 input scale
+//     u  = x * s2 + h2          s2, h2 = -log2(e) * the unscaled (s, h): the exponent of exp(-t) without a dependent multiply
 //     o  = t / (1 + 2^u)        v_exp_f32, v_add, v_rcp_f32, v_mul
-//     o  = clamp(o, +-65504)    (cannot bind for GroupNorm outputs, see the engine's guard; keeps the conversion finite)
+//     o  = clamp(o, +-65504)    (cannot bind: the scaled bound is < 2^14; keeps the conversion finite for non-finite inputs)
 //     hi = f16(o), lo = f16(o - hi) for two elements at a time (v_cvt_pk_f16_f32)
 // The four coefficients of a channel are one 16-byte LDS read.  Zero padding: a staged item outside the image never
 // changes, so its LDS slots are written once (zeros) and its per-stage stores go to a dummy slot behind the tile.
@@ -263,9 +257,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
   const int x0 = tx * 32, y0 = ty * ROWS;
+  // fp16x2 input scale of THIS utterance: the power of two that puts the bound gn_finalize_kernel derived from the utterance's
+  // own statistics (ConvArgs::xbound) in [2^13, 2^14); undone exactly on the accumulator side (inv_kx)
+  float kx = 1.f;
+  if constexpr (S::SCALED) { if (p.xbound) kx = h2_weight_scale(amax_read(p.xbound, b)); }
+  const float inv_kx = 1.f / kx;
   {
     const bool xform = p.in_scale != nullptr;
-    constexpr float kx = S::SCALED ? kH2XScale : 1.f;
     constexpr float nl2e = -1.4426950408889634f;
     for (int c = tid; c < Cin; c += 256) {
       const float sc = xform ? p.in_scale[b * Cin + c] : 1.f, sh = xform ? p.in_shift[b * Cin + c] : 0.f;
@@ -374,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) init[r] = 0.f;
     } else {
-      conv_acc_init<T>(p, b, co_blk, wc * FCW + i, kg, 1.0f, init);
+      conv_acc_init<T>(p, b, co_blk, wc * FCW + i, kg, inv_kx, init);
     }
 #pragma unroll
     for (int j = 0; j < FPW; ++j)
@@ -498,12 +496,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       }
     }
     // accumulator: from the shortcut's operand scaling (weights 2^k1, input xs) to the 3x3 stages' (acc_scale), plus the biases
-    const float as3 = *p.acc_scale;
+    const float as3 = *p.acc_scale * inv_kx;
     const float rho = (*p.sc_scale / xs) / as3;
 #pragma unroll
     for (int i = 0; i < FCW; ++i) {
       float init[16];
-      conv_acc_init<T>(p, b, co_blk, wc * FCW + i, kg, 1.0f, init);
+      conv_acc_init<T>(p, b, co_blk, wc * FCW + i, kg, inv_kx, init);
       const int co_l = co_blk * T::CO_T + (wc * FCW + i) * 32 + 4 * kg;
 #pragma unroll
       for (int r = 0; r < 16; ++r) init[r] += p.sc_bias ? p.sc_bias[co_l + (r & 3) + 8 * (r >> 2)] / as3 : 0.f;
@@ -611,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   }
 
   if constexpr (ABL & 64) { if (trace) trace[3] = drt_clock(); }
-  conv_epilogue<T, FCW, FPW, WCW, ABL & (3 | 128 | 256), !CHK>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg);
+  conv_epilogue<T, FCW, FPW, WCW, ABL & (3 | 128 | 256), !CHK>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
   if constexpr (ABL & 64) { if (trace) trace[4] = drt_clock(); }
 }
 

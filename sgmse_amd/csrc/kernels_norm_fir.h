@@ -77,9 +77,15 @@ __device__ __forceinline__ void gn_sum_pairs(const float* base, int n, double& s
 // Ragged launch (rag.w): utterance b has H * rag.w[b] pixels per plane; a source whose partials come from a convolution
 // epilogue (nsub > 1) holds them packed per utterance -- H * ceil(w / 32) sub-tiles per channel from sub-tile rag.soff[b] on,
 // exactly the layout of the utterance's own launch; gn_chan_stats sources (nsub == 1) are one pair per (b, c) either way.
+// Range bound for an fp16x2 consumer (bound_out, [B][kAmaxSpread], zeroed by the engine; null: not wanted): an upper bound of
+// |x * scale + shift| -- and with it of its SiLU, |silu(t)| <= |t| -- over the utterance, from the utterance's own data:
+//     |x - mean| <= min(max|x| + |mean|, sqrt(N var))      max|x|: the producers' range bounds amax1 / amax2 (null: unknown)
+//     bound_c = that * rstd * |gamma_c| + |beta_c|,        N var = sum of squared deviations of the group (>= any single one)
+// reduced over the group's channels here and over the groups by an atomic max (order-independent: deterministic).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* st1, int C1, int nsub1, const float* st2, int C2, int nsub2,
                                                           const float* gamma, const float* beta, int G, int HW, float eps,
-                                                          float* scale, float* shift, Rag rag, int H) {
+                                                          float* scale, float* shift, Rag rag, int H,
+                                                          const float* amax1, const float* amax2, float* bound_out) {
   __shared__ double s_s[256];
   __shared__ double s_q[256];
   const int g = blockIdx.x, b = blockIdx.y, C = C1 + C2, cpg = C / G;
@@ -107,6 +113,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* st1, int 
     if ((int)threadIdx.x < m) { s_s[threadIdx.x] += s_s[threadIdx.x + m]; s_q[threadIdx.x] += s_q[threadIdx.x + m]; }
     __syncthreads();
   }
+  float am = -1.f;                    // max |x| of the utterance over both sources; < 0: unknown
+  if (bound_out && amax1 && (C2 == 0 || amax2)) {        // (whole waves: amax_read shuffles)
+    am = amax_read(amax1, b);
+    if (C2) am = fmaxf(am, amax_read(amax2, b));
+  }
+  float bnd = 0.f;
   if ((int)threadIdx.x < cpg) {
     const int c = c_lo + threadIdx.x;
     const double n = (double)cpg * (double)HW;
@@ -117,7 +129,31 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* st1, int 
     const float a = gamma[c] * rstd;
     scale[(size_t)b * C + c] = a;
     shift[(size_t)b * C + c] = beta[c] - (float)mean * a;
+    double dev = sqrt(n * var);
+    if (am >= 0.f) dev = fmin(dev, (double)am + fabs(mean));
+    bnd = (float)(dev * (double)rstd * fabs((double)gamma[c]) + fabs((double)beta[c])) * 1.0001f;   // (margin for the fp32 affine's own rounding)
+    if (!(bnd >= 0.f)) bnd = 3.0e38f;      // NaN statistics: the result is NaN whatever the scale
   }
+  if (bound_out && threadIdx.x < 64) {     // cpg <= 64: the group's channels sit in wave 0
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, o));
+    if (threadIdx.x == 0) drt_atomic_max_nonneg(bound_out + b * kAmaxSpread + (g & (kAmaxSpread - 1)), bnd);
+  }
+}
+
+// op-level entry points / micro-benchmarks: the bound gn_finalize_kernel would have left for a producer given as explicit
+// per-channel coefficients: max_c |scale_c| m + |shift_c|, m = max|x| of the utterance (amax1 / amax2); no producer: m itself
+__global__ __launch_bounds__(64) void xform_bound_kernel(const float* scale, const float* shift, int C, const float* amax1,
+                                                         const float* amax2, float* bound_out) {
+  const int b = blockIdx.x;
+  float m = amax_read(amax1, b);
+  if (amax2) m = fmaxf(m, amax_read(amax2, b));
+  float bnd = scale ? 0.f : m;
+  if (scale)
+    for (int c = threadIdx.x; c < C; c += 64) bnd = fmaxf(bnd, fabsf(scale[(size_t)b * C + c]) * m + fabsf(shift[(size_t)b * C + c]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, o));
+  bound_out[b * kAmaxSpread + threadIdx.x] = bnd * 1.0001f;
 }
 
 // out = act(x*scale+shift); grid = (ceil(HW/1024), B*C)

@@ -247,15 +247,24 @@ def check_split_workgroup_shapes_bitwise(dev, name="fwd_nf128"):
 def adversarial_params(cfg, kind, seed=0):
     """Synthetic state dicts that stress the range handling of the fp16x2 / bf16x3 kernels (no real checkpoint is reachable
     offline): every kind must keep the network-level gate of the ordinary fixtures.
-      gn_inside   GroupNorm gamma up to 4 and beta up to 64: just inside the fp16x2 guard (engine.h: kH2GammaLimit / kH2BetaLimit)
-      gn_outside  gamma 4.5 in one module: the model must switch itself to the range-free bf16x3 kernels
+      gn_inside   GroupNorm gamma up to 4 and beta up to 64 (the limits of the round-2 worst-case guard)
+      gn_outside  gamma 4.5 in one module (beyond that guard: the per-utterance data-driven scale must keep the fp16x2 kernels)
+      gn_wild     gamma up to 8 everywhere, single channels at 30, beta up to 500
       growth      residual stream growing ~10^3 across the network (Conv_1 and the shortcut of every block scaled up)
       outliers    a few output channels of some convolutions x 10^4 (heavy-tailed activations)
       zero_init   Conv_1 of every block at the reference's init_scale=0 magnitude (1e-10, layers.py:88-91): dead branches"""
     P = synth.synth_params(cfg, seed=seed)
     g = torch.Generator().manual_seed(seed + 101)
     res_blocks = sorted({k.rsplit(".", 2)[0] for k in P if k.endswith("Conv_1.weight")}, key=lambda n: int(n.split(".")[1]))
-    if kind in ("gn_inside", "gn_outside"):
+    if kind == "gn_wild":
+        for k, v in P.items():
+            if "GroupNorm" in k and k.endswith("weight"):
+                v.copy_(0.5 + 7.5 * torch.rand(v.shape, generator=g))                    # [0.5, 8)
+                v[0] = 8.0
+                v[1] = -30.0
+            elif "GroupNorm" in k and k.endswith("bias"):
+                v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * 500.0)
+    elif kind in ("gn_inside", "gn_outside"):
         for k, v in P.items():
             if "GroupNorm" in k and k.endswith("weight"):
                 v.copy_(1.0 + 3.0 * torch.rand(v.shape, generator=g))                    # [1, 4)

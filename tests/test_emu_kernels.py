@@ -196,29 +196,31 @@ def test_enhance_end_to_end(emu):
     P.check_enhance(emu, L=8000, N=1)
 
 
-def test_extreme_groupnorm_parameters_select_the_range_free_kernels(emu, capfd):
-    """The fp16x2 3x3 kernel presumes |GroupNorm output| < 4094, guaranteed for ordinary affine parameters; a checkpoint
-    with extreme ones must get the bf16x3 kernels (reported by sgmse_conv_split_mode) and still match the oracle."""
+def test_extreme_groupnorm_parameters_keep_the_fp16x2_kernels(emu, capfd):
+    """The fp16x2 3x3 kernel scales its input per utterance by a power of two derived from the utterance's own GroupNorm statistics
+    and range bound (gn_finalize_kernel -> ConvArgs::xbound): a checkpoint with extreme affine parameters stays on the fast family
+    (sgmse_conv_split_mode == 2, nothing on stderr) and still matches the oracle."""
     cfg = P.NET_CASES["fwd_nf32"]
     Pm = P.synth.synth_params(cfg, seed=0)
-    net, _ = P.make_backbone(cfg, emu, P=Pm)
     x = torch.randn(1, 2, 256, 64, dtype=torch.complex64, generator=torch.Generator().manual_seed(3)) * 0.3
     t = torch.tensor([0.5])
-    net(x, t)
-    assert net.engine(torch.device(emu)).conv_split_mode() == 2
     Pbig = {k: v.clone() for k, v in Pm.items()}
-    name = next(k for k in Pbig if "GroupNorm_0.weight" in k)
-    Pbig[name][0] = 9.0
+    for k in Pbig:
+        if "GroupNorm" in k and k.endswith("weight"):
+            Pbig[k][0] = 9.0; Pbig[k][1] = -40.0
+        elif "GroupNorm" in k and k.endswith("bias"):
+            Pbig[k][2] = 300.0
     net2, _ = P.make_backbone(cfg, emu, P=Pbig)
     out = net2(x, t)
-    assert net2.engine(torch.device(emu)).conv_split_mode() == 1
-    assert "bf16x3" in capfd.readouterr().err
+    assert net2.engine(torch.device(emu)).conv_split_mode() == 2
+    assert "bf16x3" not in capfd.readouterr().err
     with torch.no_grad():
         ref = P.NO.ncsnpp_forward(Pbig, cfg, x, t)
     assert P.rel_l2(out, ref) < P.NET_TOL
-    net3, _ = P.make_backbone(cfg, emu, P=Pm)          # an ordinary model loaded afterwards gets fp16x2 back
-    net3(x, t)
-    assert net3.engine(torch.device(emu)).conv_split_mode() == 2
+
+
+def test_adversarial_checkpoint_wild_groupnorm_parameters(emu):
+    P.check_adversarial_checkpoint(emu, "gn_wild", nf=32, expect_mode=2)
 
 
 def test_adversarial_checkpoint_residual_stream_growth(emu):

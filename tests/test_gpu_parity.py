@@ -308,32 +308,52 @@ def test_batch_of_four_equals_four_singles_bitwise(hip):
     P.check_batch_equals_singles(hip, 4)
 
 
-@pytest.mark.parametrize("kind,mode", [("gn_inside", 2), ("gn_outside", 1), ("growth", 2), ("outliers", 2), ("zero_init", 2)])
-def test_adversarial_checkpoints_keep_the_network_gate(hip, kind, mode):
-    """Full-width network with synthetic state dicts built to stress the fp16x2 range handling (GroupNorm parameters at and
-    beyond the guard, a residual stream growing 10^3, outlier channels x 10^4, dead Conv_1 branches) against the oracle."""
-    P.check_adversarial_checkpoint(hip, kind, expect_mode=mode)
+@pytest.mark.parametrize("kind", ["gn_inside", "gn_outside", "gn_wild", "growth", "outliers", "zero_init"])
+def test_adversarial_checkpoints_keep_the_network_gate(hip, kind):
+    """Full-width network at the bench shape (T = 512) with synthetic state dicts built to stress the fp16x2 range handling
+    (GroupNorm parameters far beyond any worst-case guard, a residual stream growing 10^3, outlier channels x 10^4, dead Conv_1
+    branches) against the oracle: the per-utterance data-driven input scale keeps the fast kernel family (mode 2) every time."""
+    P.check_adversarial_checkpoint(hip, kind, T=512, expect_mode=2)
 
 
-def test_long_utterance_rechecks_the_fp16x2_range_bound(hip, capfd):
-    """The GroupNorm output bound grows with the group size: gamma = 3.9 is inside the load-time guard but 8 channels x 256 x 1024
-    frames exceed the fp16x2 range, so the engine must switch to the bf16x3 kernels when it sees that shape -- and say so."""
+def test_long_utterance_keeps_the_fp16x2_kernels(hip, capfd):
+    """Round 2 bounded a GroupNorm output by sqrt(N) max|gamma| + max|beta| and dropped the whole model to bf16x3 when an utterance
+    was long enough for that to pass 4094.  The input scale of the fp16x2 3x3 kernel now comes from the utterance's own statistics
+    (gn_finalize_kernel), so gamma = 8 with 8 x 256 x 2048-element groups stays in mode 2 -- silently -- at the network gate."""
     cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
     Pm = synth.synth_params(cfg, seed=0)
     for k, v in Pm.items():
         if "GroupNorm" in k and k.endswith("weight"):
-            v[0] = 3.9
+            v[0] = 8.0
     net, _ = P.make_backbone(cfg, hip, P=Pm)
     g = torch.Generator().manual_seed(5)
     short = torch.randn(1, 2, 256, 64, dtype=torch.complex64, generator=g) * 0.3
-    net(short.to(hip), torch.tensor([0.5], device=hip))
-    assert net.engine(torch.device(hip)).conv_split_mode() == 2
+    o_short = net(short.to(hip), torch.tensor([0.5], device=hip)).cpu()
     long = torch.randn(1, 2, 256, 2048, dtype=torch.complex64, generator=g) * 0.3
     out = net(long.to(hip), torch.tensor([0.5], device=hip))
-    assert net.engine(torch.device(hip)).conv_split_mode() == 1 and "utterance length" in capfd.readouterr().err
+    assert net.engine(torch.device(hip)).conv_split_mode() == 2 and "bf16x3" not in capfd.readouterr().err
     with torch.no_grad():
         ref = NO.ncsnpp_forward(Pm, cfg, long, torch.tensor([0.5]))
     assert rel_l2(out.cpu(), ref) < P.NET_TOL
+    # and the short utterance keeps its bits after the long one went through the same context
+    assert torch.equal(net(short.to(hip), torch.tensor([0.5], device=hip)).cpu(), o_short)
+
+
+def test_full_width_60_s_utterance_with_gamma_8_stays_on_the_fast_kernels(hip):
+    """the full-width network, GroupNorm gamma up to 8 (single channels 30, beta up to 500), one 60 s utterance
+    (T = 7552 frames: groups of 2^24 elements) -- mode 2, network gate against the oracle."""
+    cfg = NO.NetCfg.for_variant("ncsnpp")
+    Pm = P.adversarial_params(cfg, "gn_wild")
+    net, _ = P.make_backbone(cfg, hip, P=Pm)
+    x = torch.randn(1, 2, 256, 7552, dtype=torch.complex64, generator=torch.Generator().manual_seed(11)) * 0.3
+    t = torch.tensor([0.4])
+    out = net(x.to(hip), t.to(hip)).cpu()
+    assert net.engine(torch.device(hip)).conv_split_mode() == 2
+    with torch.no_grad():
+        ref = NO.ncsnpp_forward(Pm, cfg, x, t)
+    err = rel_l2(out, ref)
+    print(f"60 s utterance, full width, gamma <= 8 (30): rel_l2 vs oracle {err:.3e}")
+    assert err < P.NET_TOL
 
 
 def test_full_size_batch_independence(hip):
