@@ -15,6 +15,10 @@ FULL_CASES = {
     # configs[3]: ncsnpp_48k, F=768, T=128 (0.96 s @48 kHz: 121 frames, reflection-padded), PC N=50, snr=0.33 (100 NFE)
     "pc48k_full": dict(variant="ncsnpp_48k", L=46080, front="ears", pad="reflection", sampler="pc", N=50, snr=0.33,
                        sde=dict(theta=2.0, sigma_min=0.1, sigma_max=1.0), wave_seed=0, noise_seed=7, param_seed=0),
+    # configs[3] at the BENCHED shape: 4 s @48 kHz (501 frames -> T=512, F=768), PC with N=5 (10 NFE: what fits a CPU run of the
+    # reference, ~40 s per evaluation) -- pins the 48 kHz sampler and network at full length
+    "pc48k_T512": dict(variant="ncsnpp_48k", L=192000, front="ears", pad="reflection", sampler="pc", N=5, snr=0.33,
+                       sde=dict(theta=2.0, sigma_min=0.1, sigma_max=1.0), wave_seed=0, noise_seed=7, param_seed=0),
 }
 
 

@@ -126,6 +126,22 @@ def check_tensor(t: torch.Tensor, name: str, dtype: torch.dtype, device: torch.d
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _ragged_geometry(items, planes: int, what: str):
+    """Frame counts and the common F of a ragged batch: every element [planes,F,T_b] (or [F,T_b] when planes == 1).  The packed
+    buffer and the engine's own size arithmetic (sum F*T_b) must agree, so mismatching shapes are refused here."""
+    if len(items) == 0:
+        raise ValueError(f"ragged batch: empty list of {what}")
+    F_ = int(items[0].shape[-2]) if items[0].dim() >= 2 else -1
+    frames = []
+    for i, v in enumerate(items):
+        ok = v.dim() in ((2, 3) if planes == 1 else (3,)) and int(v.shape[-2]) == F_ and v.numel() == planes * F_ * int(v.shape[-1])
+        if not ok:
+            raise ValueError(f"ragged batch: {what}[{i}] has shape {tuple(v.shape)}; every utterance must be "
+                             f"[{planes},{F_},T_b]" + (" or [F,T_b]" if planes == 1 else ""))
+        frames.append(int(v.shape[-1]))
+    return frames, F_
+
+
 class Context:
     """One sgmse_ctx: a device, a stream, the weights and the activation arena."""
 
@@ -257,8 +273,8 @@ class Context:
         if isinstance(Y, (list, tuple)):       # ragged batch: utterances [F,T_b] (or [1,F,T_b]) of different lengths, see set_frames
             if noise is not None:
                 raise ValueError("ragged batches use in-kernel noise only")
-            frames = [int(y.shape[-1]) for y in Y]
-            F_, B, T = int(Y[0].shape[-2]), len(Y), max(frames)
+            frames, F_ = _ragged_geometry(Y, 1, "y")
+            B, T = len(Y), max(frames)
             Y = torch.cat([check_tensor(y, "y", torch.complex64, self.device).reshape(-1) for y in Y])
         else:
             Y = check_tensor(Y, "y", torch.complex64, self.device)
@@ -413,8 +429,7 @@ class Context:
     def forward_ragged(self, xys, t: torch.Tensor):
         """NCSNpp.forward on utterances of different lengths in ONE batch: xys = list of complex64 [2,F,T_b]; returns the list of
         complex64 [1,F,T_b], each bit-identical to ``forward(xy[None], t[b:b+1])[0]``."""
-        frames = [int(x.shape[-1]) for x in xys]
-        F_ = int(xys[0].shape[-2])
+        frames, F_ = _ragged_geometry(xys, 2, "x")
         packed = torch.cat([check_tensor(x, "x", torch.complex64, self.device).reshape(-1) for x in xys])
         t = check_tensor(t.reshape(-1), "time_cond", torch.float32, self.device)
         if t.numel() != len(xys):

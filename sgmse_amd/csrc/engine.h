@@ -286,6 +286,8 @@ class Engine {
     for (void* p : owned_) drt::free_dev(p);
     for (void* p : wowned_) drt::free_dev(p);
     if (graph_valid_) drt::graph_destroy(&graph_);
+    if (hstage_) drt::free_host(hstage_);
+    if (hstage_ev_init_) drt::event_destroy(&hstage_ev_);
   }
 
   drt::stream_t stream() const { return stream_; }
@@ -373,14 +375,12 @@ class Engine {
     }
     const bool affine = sc.in_scale && sc.score_alpha && sc.score_beta;
     SG_REQUIRE(affine || (!sc.in_scale && !sc.score_alpha && !sc.score_beta), "pc_sample: give all three score-wrapper arrays or none");
+    std::vector<float> cf;
     if (affine) {
-      std::vector<float> cf((size_t)sc.N * 4, 0.f);
+      cf.assign((size_t)sc.N * 4, 0.f);
       for (int i = 0; i < sc.N; ++i) { cf[4 * i] = sc.in_scale[i]; cf[4 * i + 1] = sc.score_alpha[i]; cf[4 * i + 2] = sc.score_beta[i]; }
-      SG_CHECK(drt::memcpy_h2d(coef_table_, cf.data(), cf.size() * 4, stream_));
     }
-    SG_CHECK(drt::memcpy_h2d(step_table_, tab.data(), tab.size() * 4, stream_));
-    SG_CHECK(drt::memcpy_h2d(tsteps_, tv.data(), tv.size() * 4, stream_));
-    SG_CHECK(drt::stream_sync(stream_));
+    const unsigned long long* seed_dev = upload_tables(tab, tv, cf, seed, B);      // no host synchronisation (pinned staging)
     compute_temb(tsteps_, sc.N);
 
     const int ncorr = sc.corrector ? sc.corrector_steps : 0;
@@ -390,7 +390,7 @@ class Engine {
     SG_CHECK(drt::memcpy_d2d(sy_, Y, n * 8, stream_));   // engine-owned copy: the captured graph never refers to caller memory
     Y = sy_;
     SamplerArgs sa{};
-    sa.x = sx_; sa.x_mean = sxm_; sa.y = Y; sa.score = sscore_; sa.noise = noise; sa.seed = set_seed(seed, B);
+    sa.x = sx_; sa.x_mean = sxm_; sa.y = Y; sa.score = sscore_; sa.noise = noise; sa.seed = seed_dev;
     sa.table = step_table_; sa.step_ptr = step_ctr_; sa.theta = sc.theta; sa.std1 = sc.std1; sa.n = (int)n;
     sa.score_w = sc.probability_flow ? 0.5f : 1.0f;
     sa.snr = sc.snr; sa.B = B; sa.per = F * T; sa.partial = lang_partial_; sa.lang = lang_scal_;
@@ -466,21 +466,19 @@ class Engine {
     }
     const bool affine = in_scale && alpha && beta;
     SG_REQUIRE(affine || (!in_scale && !alpha && !beta), "sb_sample: give all three score-wrapper arrays or none");
+    std::vector<float> cf;
     if (affine) {
-      std::vector<float> cf((size_t)N * 4, 0.f);
+      cf.assign((size_t)N * 4, 0.f);
       for (int i = 0; i < N; ++i) { cf[4 * i] = in_scale[i]; cf[4 * i + 1] = alpha[i]; cf[4 * i + 2] = beta[i]; }
-      SG_CHECK(drt::memcpy_h2d(coef_table_, cf.data(), cf.size() * 4, stream_));
     }
-    SG_CHECK(drt::memcpy_h2d(step_table_, tab.data(), tab.size() * 4, stream_));
-    SG_CHECK(drt::memcpy_h2d(tsteps_, tv.data(), tv.size() * 4, stream_));
-    SG_CHECK(drt::stream_sync(stream_));
+    const unsigned long long* seed_dev = upload_tables(tab, tv, cf, seed, B);
     compute_temb(tsteps_, N);
     SG_CHECK(drt::memcpy_d2d(sy_, Y, n * 8, stream_));
     SG_CHECK(drt::memcpy_d2d(sx_, Y, n * 8, stream_));          // x_0 = y
     DRT_LAUNCH(step_set_kernel, dim3(1), dim3(64), stream_, step_ctr_, 0);
 
     SamplerArgs sa{};
-    sa.x = sx_; sa.x_mean = sxm_; sa.y = sy_; sa.score = sscore_; sa.noise = noise; sa.seed = set_seed(seed, B);
+    sa.x = sx_; sa.x_mean = sxm_; sa.y = sy_; sa.score = sscore_; sa.noise = noise; sa.seed = seed_dev;
     sa.table = step_table_; sa.step_ptr = step_ctr_; sa.n = (int)n; sa.add_noise = stochastic ? 1 : 0; sa.B = B; sa.per = F * T;
     sa.draw_base = 0; sa.draw_per_step = 1;
     const dim3 eg((unsigned)((n + 255) / 256));
@@ -1540,7 +1538,7 @@ class Engine {
   }
 
   // what a captured step depends on.  The Philox seed is NOT part of it: the sampler kernels read it from a device word
-  // (set_seed), so one capture serves every utterance / batch of a run (the Python samplers draw a fresh seed per call)
+  // (upload_tables), so one capture serves every utterance / batch of a run (the Python samplers draw a fresh seed per call)
   struct GraphKey {
     int B, F, T, corr, ncorr, pred, pf; const void* y; const void* noise; float theta; int dps;
     bool operator==(const GraphKey& o) const {
@@ -1548,23 +1546,46 @@ class Engine {
              noise == o.noise && theta == o.theta && dps == o.dps;
     }
   };
-  // seed word + one noise-stream id per utterance (SamplerArgs::seed); ids given by set_noise_streams are consumed by the next
-  // sampler call of the same batch size, otherwise utterance b gets stream b
-  const unsigned long long* set_seed(unsigned long long seed, int B) {
+  // Per-call sampler constants -> device: the step table, the time steps, the score-wrapper rows (may be empty) and the noise
+  // table -- seed word + one noise-stream id per utterance (SamplerArgs::seed; ids given by set_noise_streams are consumed by the
+  // next sampler call of the same batch size, otherwise utterance b gets stream b).  The host side of the copies is ONE page-locked
+  // staging buffer, so the copies are asynchronous and a sampler call never synchronises the host with the stream (no
+  // hidden host syncs): the caller may already enqueue the next batch's front end while this one samples.  The staging buffer is
+  // reused by the next call once the event recorded behind these copies has passed (it has, long before: the copies are the
+  // first thing a call enqueues).
+  const unsigned long long* upload_tables(const std::vector<float>& tab, const std::vector<float>& tv, const std::vector<float>& cf,
+                                          unsigned long long seed, int B) {
     SG_REQUIRE(B + 1 <= kMaxStreams, "batch too large for the noise-stream table");
     if (!seed_dev_) seed_dev_ = static_cast<unsigned long long*>(dev_alloc((size_t)kMaxStreams * 8));
-    seed_host_.assign((size_t)B + 1, 0ull);
-    seed_host_[0] = seed;
+    const size_t nb_seed = ((size_t)B + 1) * 8, nb_tab = tab.size() * 4, nb_tv = tv.size() * 4, nb_cf = cf.size() * 4;
+    const size_t total = nb_seed + nb_tab + nb_tv + nb_cf;
+    if (hstage_pending_) { SG_CHECK(drt::event_sync(&hstage_ev_)); hstage_pending_ = false; }
+    if (total > hstage_cap_) {
+      if (hstage_) drt::free_host(hstage_);
+      hstage_cap_ = std::max(total, size_t(1) << 16);
+      SG_CHECK(drt::malloc_host(reinterpret_cast<void**>(&hstage_), hstage_cap_));
+    }
+    unsigned long long* hs = reinterpret_cast<unsigned long long*>(hstage_);
+    hs[0] = seed;
     const bool given = (int)streams_next_.size() == B;
-    for (int b = 0; b < B; ++b) seed_host_[1 + b] = given ? streams_next_[b] : (unsigned long long)b;
+    for (int b = 0; b < B; ++b) hs[1 + b] = given ? streams_next_[b] : (unsigned long long)b;
     streams_next_.clear();
-    SG_CHECK(drt::memcpy_h2d(seed_dev_, seed_host_.data(), seed_host_.size() * 8, stream_));
-    SG_CHECK(drt::stream_sync(stream_));
+    char* q = hstage_ + nb_seed;
+    memcpy(q, tab.data(), nb_tab); memcpy(q + nb_tab, tv.data(), nb_tv);
+    if (nb_cf) memcpy(q + nb_tab + nb_tv, cf.data(), nb_cf);
+    SG_CHECK(drt::memcpy_h2d(seed_dev_, hs, nb_seed, stream_));
+    SG_CHECK(drt::memcpy_h2d(step_table_, q, nb_tab, stream_));
+    SG_CHECK(drt::memcpy_h2d(tsteps_, q + nb_tab, nb_tv, stream_));
+    if (nb_cf) SG_CHECK(drt::memcpy_h2d(coef_table_, q + nb_tab + nb_tv, nb_cf, stream_));
+    if (!hstage_ev_init_) { SG_CHECK(drt::event_create(&hstage_ev_)); hstage_ev_init_ = true; }
+    SG_CHECK(drt::event_record(&hstage_ev_, stream_));
+    hstage_pending_ = true;
     return seed_dev_;
   }
+  char* hstage_ = nullptr; size_t hstage_cap_ = 0; drt::event_t hstage_ev_{}; bool hstage_ev_init_ = false, hstage_pending_ = false;
   static constexpr int kMaxStreams = 4096;
   std::vector<unsigned long long> streams_next_;
-  unsigned long long* seed_dev_ = nullptr; std::vector<unsigned long long> seed_host_;
+  unsigned long long* seed_dev_ = nullptr;
   int graph_captures_ = 0;
 
   int device_;

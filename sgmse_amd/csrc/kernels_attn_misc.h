@@ -352,9 +352,12 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
 }
 
 // complex standard normal (Re, Im ~ N(0, 1/2)), what torch.randn_like gives for complex64
-__device__ __forceinline__ float2 philox_cnormal(unsigned long long seed, unsigned long long idx, uint32_t draw, uint32_t stream = 0) {
+// stream: 64-bit noise-stream id of the utterance; its low word enters the counter (as it always did, so ids below 2^32 keep their
+// draws), its high word the key, so ids that differ only above bit 31 (hashed utterance ids) get different streams too
+__device__ __forceinline__ float2 philox_cnormal(unsigned long long seed, unsigned long long idx, uint32_t draw, unsigned long long stream64 = 0) {
+  const uint32_t stream = (uint32_t)stream64, shi = (uint32_t)(stream64 >> 32);
   uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32) ^ (stream * 0x9E3779B9u), c2 = draw, c3 = 0x5367534du ^ stream;
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t k0 = (uint32_t)seed ^ (shi * 0x85EBCA6Bu), k1 = (uint32_t)(seed >> 32) ^ shi;
 #pragma unroll
   for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
   const float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
@@ -391,10 +394,10 @@ __device__ __forceinline__ float2 sampler_noise(const SamplerArgs& p, int i, int
   if (p.rag_off) {            // the utterance this element belongs to: last b with rag_off[b] <= i
     int lo = 0, hi = p.B;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.rag_off[mid] <= (long long)i) lo = mid; else hi = mid; }
-    return philox_cnormal(p.seed[0], (unsigned long long)((long long)i - p.rag_off[lo]), (uint32_t)draw, (uint32_t)p.seed[1 + lo]);
+    return philox_cnormal(p.seed[0], (unsigned long long)((long long)i - p.rag_off[lo]), (uint32_t)draw, p.seed[1 + lo]);
   }
   const int b = i / p.per;
-  return philox_cnormal(p.seed[0], (unsigned long long)(i - b * p.per), (uint32_t)draw, (uint32_t)p.seed[1 + b]);
+  return philox_cnormal(p.seed[0], (unsigned long long)(i - b * p.per), (uint32_t)draw, p.seed[1 + b]);
 }
 
 __global__ __launch_bounds__(256) void sampler_prior_kernel(SamplerArgs p) {

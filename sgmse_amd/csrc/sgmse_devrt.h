@@ -106,6 +106,9 @@ inline const char* backend_name() { return "hip-gfx950"; }
 inline int set_device(int d) { return int(hipSetDevice(d)); }
 inline int malloc_dev(void** p, size_t n) { return int(hipMalloc(p, n)); }
 inline int free_dev(void* p) { return int(hipFree(p)); }
+// page-locked host memory: the source of host-to-device copies that must not block the calling thread
+inline int malloc_host(void** p, size_t n) { return int(hipHostMalloc(p, n, hipHostMallocDefault)); }
+inline int free_host(void* p) { return int(hipHostFree(p)); }
 inline int memcpy_h2d(void* d, const void* s, size_t n, stream_t st) { return int(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st)); }
 inline int memcpy_d2h(void* d, const void* s, size_t n, stream_t st) { return int(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st)); }
 inline int memcpy_d2d(void* d, const void* s, size_t n, stream_t st) { return int(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st)); }

@@ -13,10 +13,13 @@ Differences from the reference script, none of them in the arithmetic of one utt
 * with ``--ragged`` files of DIFFERENT padded lengths share a batch too (``sgmse_set_frames``: every kernel addresses an
   utterance's block with the utterance's own row stride, so its arithmetic is still that of its single-file run, bit for bit):
   full batches of one padded length still run as uniform batches, the leftovers of all lengths are pooled, sorted by length and
-  cut into ragged batches of ``--batch_size`` (a ragged batch costs 1.16 x a uniform one per frame, a small uniform batch more);
+  cut into ragged batches of ``--batch_size`` when the measured cost model (``plan_batches``) says that beats the small
+  bucketed batches;
 * under ``torchrun`` every rank takes a contiguous shard of the sorted file list (the split of the reference's validation
-  loop, ``model.py:212-223``), rank 0 reads the checkpoint and the weights reach the other ranks in one RCCL broadcast; there
-  is no collective on the data path;
+  loop, ``model.py:212-223``) or, with ``--balance frames``, a longest-processing-time share by padded frame count; rank 0
+  reads the checkpoint and the weights reach the other ranks in one RCCL broadcast; there is no collective on the data path;
+* every file is read / resampled once on background threads ahead of the GPU, and the inverse transform + file writes of a
+  batch overlap the sampling of the next one;
 * audio I/O uses ``soundfile`` when it is installed and ``scipy.io.wavfile`` (wav only) otherwise; resampling to the
   model's rate uses ``scipy.signal.resample_poly`` (the reference: ``librosa.resample``).
 """
@@ -111,67 +114,237 @@ def _load_normalised(path: str, target_sr: int) -> Tuple[torch.Tensor, float]:
     return torch.from_numpy(y / peak), peak
 
 
-def enhance_files(model: ScoreModel, files: List[str], test_dir: str, enhanced_dir: str, args, device, first_index: int = 0) -> int:
-    """Enhance ``files`` in batches.  What has to agree inside a batch is the PADDED spectrogram shape, not the waveform
+RAGGED_COST = 1.16          # GPU time per frame of a ragged batch relative to a uniform one (profiles/r02_ragged_bench.txt)
+
+
+def probe_samples(path: str, target_sr: int) -> int:
+    """Number of samples the file has at the model's rate, from its HEADER (no decoding, no resampling): what the batching and the
+    rank assignment are planned from.  ``resample_poly`` yields ceil(n * up / down) samples."""
+    try:
+        import soundfile
+        info = soundfile.info(path)
+        n, sr = int(info.frames), int(info.samplerate)
+    except ImportError:
+        from scipy.io import wavfile
+        try:
+            sr, x = wavfile.read(path, mmap=True)          # maps the data chunk: the header gives the shape
+            n = int(x.shape[0])
+            del x
+        except ValueError:                                  # a sample format scipy cannot map
+            sr, x = wavfile.read(path)
+            n = int(x.shape[0])
+    if sr == target_sr:
+        return n
+    g = gcd(sr, target_sr)
+    up, down = target_sr // g, sr // g
+    return -(-n * up // down)
+
+
+def padded_frames(n_samples: int, hop: int) -> int:
+    """Frames of the padded spectrogram of an n-sample waveform: centred STFT (n // hop + 1 frames, data_module.py:212-214), then
+    ``pad_spec`` to the next multiple of 64 (util/other.py:76-90)."""
+    return (n_samples // hop + 1 + 63) // 64 * 64
+
+
+def assign_files(frames: List[int], rank: int, world: int, balance: str) -> List[int]:
+    """Indices (into the sorted file list) of the files of ``rank``.
+
+    'contiguous': the reference's split (model.py:212-223): equal contiguous shards, remainder to the last rank.
+    'frames':     longest-processing-time assignment by padded frame count -- files by decreasing length (ties by index), each to
+                  the rank with the fewest frames so far (ties to the lowest rank).  Every rank computes the same table from the
+                  headers alone.  An utterance's noise is a function of (seed, its index in the file list), never of its rank or
+                  batch, so the enhanced files are the same under either assignment."""
+    if balance == "contiguous" or world == 1:
+        lo, hi = shard_range(len(frames), rank, world)
+        return list(range(lo, hi))
+    if balance != "frames":
+        raise ValueError(f"--balance {balance} not supported")
+    load = [0] * world
+    mine: List[int] = []
+    for i in sorted(range(len(frames)), key=lambda k: (-frames[k], k)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += frames[i]
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
+
+
+def plan_batches(idx: List[int], frames: List[int], batch_size: int, ragged: bool, ragged_factor: float = RAGGED_COST) -> List[List[int]]:
+    """Batches of file indices.  Uniform batches hold files of ONE padded frame count.  With ``ragged`` the leftovers of every
+    length (what does not fill a uniform batch) are pooled, shortest first, and cut into ragged batches -- unless the cost model
+    says the bucketed leftovers are cheaper: a ragged batch costs ``ragged_factor`` x its frames (measured,
+    profiles/r03_ragged_bench.txt), a uniform batch of n < batch_size utterances its frames x the small-batch penalty
+    ``batch_cost(n)`` (measured batch-1 / batch-8 / batch-32 rates)."""
+    by_frames: Dict[int, List[int]] = {}
+    for i in idx:
+        by_frames.setdefault(frames[i], []).append(i)
+    if not ragged:
+        return [g[k:k + batch_size] for _, g in sorted(by_frames.items()) for k in range(0, len(g), batch_size)]
+    batches, rest = [], []
+    for _, g in sorted(by_frames.items()):
+        nfull = len(g) // batch_size * batch_size
+        batches += [g[k:k + batch_size] for k in range(0, nfull, batch_size)]
+        if nfull < len(g):
+            rest.append(g[nfull:])
+    pooled = sorted((i for g in rest for i in g), key=lambda i: (frames[i], i))
+    ragged_batches = [pooled[k:k + batch_size] for k in range(0, len(pooled), batch_size)]
+    cost_bucketed = sum(batch_cost(len(g)) * sum(frames[i] for i in g) for g in rest)
+    cost_ragged = sum((ragged_factor if len({frames[i] for i in g}) > 1 else 1.0) * batch_cost(len(g)) * sum(frames[i] for i in g)
+                      for g in ragged_batches)
+    return batches + (ragged_batches if cost_ragged < cost_bucketed else rest)
+
+
+def batch_cost(n: int) -> float:
+    """GPU time per utterance-frame of a uniform batch of n utterances relative to batch 32, interpolated in log2(n) between the
+    measured rates 2.2 (n=1), 4.6 (n=8) and 5.1 utt/s (n=32)."""
+    import math
+    pts = [(0.0, 5.1 / 2.2), (3.0, 5.1 / 4.6), (5.0, 1.0)]
+    x = min(max(math.log2(max(n, 1)), 0.0), 5.0)
+    for (x0, y0), (x1, y1) in zip(pts, pts[1:]):
+        if x <= x1:
+            return y0 + (y1 - y0) * (x - x0) / (x1 - x0)
+    return 1.0
+
+
+class _Writer:
+    """Background thread that finishes a batch while the next one samples: waits for the device-to-host copy of the enhanced
+    waveforms (an event on the stream they were produced on), undoes the peak normalisation and writes the files."""
+
+    def __init__(self):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=4)
+        self.err = None
+        self.done = 0
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            try:
+                event, items = job
+                if event is not None:
+                    event.synchronize()
+                for host, peak, out_path, sr in items:
+                    write_audio(out_path, host.numpy() * peak, sr)                 # renormalise (enhancement.py:102)
+                    self.done += 1
+            except Exception as e:      # noqa: BLE001 -- re-raised on the main thread by close()
+                self.err = e
+
+    def put(self, event, items):
+        if self.err is not None:
+            raise self.err
+        self.q.put((event, items))
+
+    def close(self) -> int:
+        self.q.put(None)
+        self.th.join()
+        if self.err is not None:
+            raise self.err
+        return self.done
+
+
+def enhance_files(model: ScoreModel, files: List[str], test_dir: str, enhanced_dir: str, args, device, first_index: int = 0,
+                  indices=None, frames=None) -> int:
+    """Enhance ``files`` in batches.  What has to agree inside a (uniform) batch is the PADDED spectrogram shape, not the waveform
     length: every utterance goes through its own STFT and its own ``pad_spec`` (zero / reflection padding to the next multiple
     of 64 frames, exactly what the reference does per file), utterances with the same padded frame count are stacked, sampled
     together and inverted one by one with their own lengths.  A corpus of mixed lengths therefore runs in batches (64 frames =
     0.5 s at 16 kHz granularity) while every utterance keeps the arithmetic of its single-file run bit for bit.  With ``--seed``
     the noise of an utterance is a function of (seed, its index in the sorted file list): the enhanced files do not depend on
-    the batch size, the bucket an utterance landed in or the number of ranks."""
+    the batch size, the bucket an utterance landed in or the number of ranks.
+
+    Plumbing (none of it touches an utterance's arithmetic): the batches are planned from the file HEADERS; every file is read,
+    resampled and peak-normalised once, on a pool of background threads that runs ahead of the GPU; waveforms of one length share
+    one STFT launch; the sampler call does not synchronise the host, so the inverse transform, the device-to-host copy and the
+    file writes of batch k (a writer thread waiting on an event) overlap the sampling of batch k + 1.
+
+    ``indices``: the global index (noise stream id) of every file; default ``first_index + position``.  ``frames``: their padded
+    frame counts if the caller already probed the headers."""
+    from concurrent.futures import ThreadPoolExecutor
     target_sr, pad_mode = model_audio_settings(model)
     hop = model.data_module.hop_length
-    by_frames: Dict[int, List[str]] = {}
-    lengths: Dict[str, int] = {}
-    for path in files:                                   # pass 1: lengths only (headers would do; files are small)
-        y, _ = _load_normalised(path, target_sr)
-        lengths[path] = len(y)
-        frames = len(y) // hop + 1
-        by_frames.setdefault((frames + 63) // 64 * 64, []).append(path)
-    index = {path: first_index + k for k, path in enumerate(files)}
+    n = len(files)
+    gidx = list(indices) if indices is not None else [first_index + k for k in range(n)]
+    if frames is None:
+        frames = [padded_frames(probe_samples(p, target_sr), hop) for p in files]
     ragged = bool(getattr(args, "ragged", False))
     if ragged and (model.sde.__class__.__name__ != "OUVESDE" or args.corrector == "langevin"):
         import warnings
         warnings.warn("--ragged needs an OUVE model and the 'ald' / 'none' corrector (the Langevin corrector couples the utterances of "
                       "a batch; the Schroedinger-bridge sampler is not built for it): batching by padded length instead")
         ragged = False
-    if ragged:
-        # full batches of one padded length run as uniform batches (the fastest form); what is left over of every length is pooled,
-        # shortest first (neighbours in a batch have similar lengths), and cut into ragged batches of any mix of lengths
-        batches, rest = [], []
-        for _, paths in sorted(by_frames.items()):
-            nfull = len(paths) // args.batch_size * args.batch_size
-            batches += [paths[i:i + args.batch_size] for i in range(0, nfull, args.batch_size)]
-            rest += paths[nfull:]
-        rest.sort(key=lambda p: (lengths[p], p))
-        batches += [rest[i:i + args.batch_size] for i in range(0, len(rest), args.batch_size)]
-    else:
-        batches = [paths[i:i + args.batch_size] for _, paths in sorted(by_frames.items()) for i in range(0, len(paths), args.batch_size)]
-    done = 0
-    for chunk in batches:
-        specs, peaks = [], []
-        for path in chunk:
-            y, peak = _load_normalised(path, target_sr)
-            Y = model._forward_transform(model._stft(y[None].to(device))).unsqueeze(1)      # [1,1,F,frames]
-            specs.append(pad_spec(Y, mode=pad_mode))
-            peaks.append(peak)
-        uniform = len({int(Y.shape[-1]) for Y in specs}) == 1
-        Ys = torch.cat(specs) if uniform else [Y[0] for Y in specs]                         # ragged: list of [1,F,T_b]
-        sample, _ = build_sampler(model, Ys, args, args.seed, [index[p] for p in chunk])()
-        for j, path in enumerate(chunk):
-            spec = sample[j:j + 1, 0] if uniform else sample[j]
-            x = model.to_audio(spec, lengths[path])[0].cpu().numpy()                        # spec_back + iSTFT (enhancement.py:99)
-            name = path.replace(test_dir, "")
-            name = name[1:] if name.startswith("/") else name
-            write_audio(join(enhanced_dir, name), x * peaks[j], target_sr)                  # renormalise (enhancement.py:102)
-            done += 1
+    batches = plan_batches(list(range(n)), frames, args.batch_size, ragged)
+    on_gpu = device.type == "cuda"
+    pool = ThreadPoolExecutor(max_workers=int(getattr(args, "io_threads", 4) or 4))
+    ahead = 2                                                  # batches whose files are loading while one samples
+    loads: Dict[int, object] = {}
+
+    def submit(bi):
+        if bi < len(batches):
+            for k in batches[bi]:
+                loads[k] = pool.submit(_load_normalised, files[k], target_sr)
+
+    for bi in range(min(ahead, len(batches))):
+        submit(bi)
+    writer = _Writer()
+    try:
+        for bi, chunk in enumerate(batches):
+            submit(bi + ahead)
+            waves = {k: loads.pop(k).result() for k in chunk}          # (waveform, peak)
+            # one STFT launch per distinct waveform length of the batch (a fixed-length corpus: one launch)
+            specs: Dict[int, torch.Tensor] = {}
+            by_len: Dict[int, List[int]] = {}
+            for k in chunk:
+                by_len.setdefault(int(waves[k][0].numel()), []).append(k)
+            for L, ks in by_len.items():
+                y = torch.stack([waves[k][0] for k in ks])
+                if on_gpu:
+                    y = y.pin_memory().to(device, non_blocking=True)
+                Y = pad_spec(model._forward_transform(model._stft(y)).unsqueeze(1), mode=pad_mode)      # [n,1,F,T]
+                for j, k in enumerate(ks):
+                    specs[k] = Y[j:j + 1]
+            # the header-based plan holds unless a header lied: group by the ACTUAL padded shape and run every group on its own
+            # (a uniform batch that turns out mixed would otherwise fall into the ragged path of a sampler that may not take it)
+            groups: Dict[int, List[int]] = {}
+            for k in chunk:
+                groups.setdefault(int(specs[k].shape[-1]), []).append(k)
+            runs = [chunk] if (len(groups) == 1 or ragged) else list(groups.values())
+            for run in runs:
+                uniform = len({int(specs[k].shape[-1]) for k in run}) == 1
+                Ys = torch.cat([specs[k] for k in run]) if uniform else [specs[k][0] for k in run]      # ragged: list of [1,F,T_b]
+                sample, _ = build_sampler(model, Ys, args, args.seed, [gidx[k] for k in run])()
+                items = []
+                for j, k in enumerate(run):
+                    spec = sample[j:j + 1, 0] if uniform else sample[j]
+                    x = model.to_audio(spec, int(waves[k][0].numel()))[0]                               # spec_back + iSTFT (enhancement.py:99)
+                    if on_gpu:
+                        host = torch.empty(x.shape, dtype=x.dtype, pin_memory=True)
+                        host.copy_(x, non_blocking=True)
+                    else:
+                        host = x.cpu()
+                    name = files[k].replace(test_dir, "")
+                    name = name[1:] if name.startswith("/") else name
+                    items.append((host, waves[k][1], join(enhanced_dir, name), target_sr))
+                event = None
+                if on_gpu:
+                    event = torch.cuda.Event()
+                    event.record(torch.cuda.current_stream(device))
+                writer.put(event, items)
+    finally:
+        pool.shutdown(wait=False, cancel_futures=True)
+        done = writer.close()
     return done
 
 
 def load_model(ckpt: str, device, rank: int, world: int) -> ScoreModel:
     """Single process: read the checkpoint.  Several ranks with an initialised process group: rank 0 reads it (and swaps the
-    EMA weights in), the others build the same architecture from the broadcast hyper-parameters and receive the weights in
-    ONE broadcast over RCCL/xGMI (parallel.broadcast_backbone_weights) -- the only collective of the job."""
+    EMA weights in), the others build the same architecture from the broadcast hyper-parameters -- EVERY constructor argument,
+    the score wrapper's (c_in / c_out / c_skip / network_scaling / sigma_data / loss_type) included -- and receive the weights
+    in ONE broadcast over RCCL/xGMI (parallel.broadcast_backbone_weights) -- the only collective of the job."""
     import torch.distributed as dist
     if world == 1 or not (dist.is_available() and dist.is_initialized()):
         model = ScoreModel.load_from_checkpoint(ckpt, map_location=device)
@@ -207,7 +380,12 @@ def main(argv=None) -> int:
     parser.add_argument("--t_eps", type=float, default=0.03, help="The minimum process time (0.03 by default)")
     parser.add_argument("--batch_size", type=int, default=32, help="Utterances of equal padded length enhanced together")
     parser.add_argument("--seed", type=int, default=None, help="Base seed of the sampler noise (default: unseeded, like the reference)")
-    parser.add_argument("--ragged", action="store_true", help="Batch files of different padded lengths together (OUVE models, pc / ode samplers, ald / none correctors)")
+    parser.add_argument("--ragged", action="store_true", help="Batch files of different padded lengths together where the cost model says it pays "
+                                                              "(OUVE models, pc / ode samplers, ald / none correctors)")
+    parser.add_argument("--balance", type=str, choices=("contiguous", "frames"), default="contiguous",
+                        help="Files per rank under torchrun: the reference's contiguous split of the sorted list (default), or balanced by "
+                             "padded frame count (longest-processing-time); the enhanced files are identical either way")
+    parser.add_argument("--io_threads", type=int, default=4, help="Background threads that read / resample the next batches' files")
     args = parser.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -227,9 +405,14 @@ def main(argv=None) -> int:
     model.to(device)
 
     files = list_audio(args.test_dir)
-    lo, hi = shard_range(len(files), rank, world)
-    n = enhance_files(model, files[lo:hi], args.test_dir, args.enhanced_dir, args, device, first_index=lo)
-    print(f"[rank {rank}/{world}] enhanced {n} of {len(files)} files into {args.enhanced_dir}")
+    target_sr, _ = model_audio_settings(model)
+    hop = model.data_module.hop_length
+    frames = [padded_frames(probe_samples(p, target_sr), hop) for p in files]      # headers only; every rank sees the same table
+    mine = assign_files(frames, rank, world, args.balance)
+    n = enhance_files(model, [files[i] for i in mine], args.test_dir, args.enhanced_dir, args, device, indices=mine,
+                      frames=[frames[i] for i in mine])
+    print(f"[rank {rank}/{world}] enhanced {n} of {len(files)} files ({sum(frames[i] for i in mine)} of {sum(frames)} padded frames) "
+          f"into {args.enhanced_dir}")
     if started_pg:
         dist.barrier()
         dist.destroy_process_group()

@@ -74,8 +74,12 @@ class ScoreModel(nn.Module):
         self.l1_weight, self.pesq_weight = l1_weight, pesq_weight
         self.network_scaling, self.c_in, self.c_out, self.c_skip, self.sigma_data = network_scaling, c_in, c_out, c_skip, sigma_data
         self.num_eval_files, self.sr = num_eval_files, sr
+        # every constructor argument, as the reference's save_hyperparameters(ignore=['no_wandb']) keeps them (model.py:87):
+        # ScoreModel(**model.hparams) rebuilds the same model, score wrapper included (the torchrun path of the directory script)
         self.hparams = dict(backbone=backbone, sde=sde, lr=lr, ema_decay=ema_decay, t_eps=t_eps, num_eval_files=num_eval_files,
-                            loss_type=loss_type, sr=sr, data_module_cls=data_module_cls, **kwargs)
+                            loss_type=loss_type, loss_weighting=loss_weighting, network_scaling=network_scaling, c_in=c_in,
+                            c_out=c_out, c_skip=c_skip, sigma_data=sigma_data, l1_weight=l1_weight, pesq_weight=pesq_weight,
+                            sr=sr, data_module_cls=data_module_cls, **kwargs)
         data_module_cls = SpecsDataModule if data_module_cls is None else data_module_cls
         self.data_module = data_module_cls(**kwargs, gpu=kwargs.get("gpus", 0) > 0)
         # EMA bookkeeping (what torch_ema's store / copy_to / restore do for the reference, model.py:111-122)

@@ -123,6 +123,8 @@ inline const char* backend_name() { return "cpu-emulator(test-only)"; }
 inline int set_device(int) { return 0; }
 inline int malloc_dev(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? 0 : 1; }
 inline int free_dev(void* p) { free(p); return 0; }
+inline int malloc_host(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 1; }
+inline int free_host(void* p) { free(p); return 0; }
 inline int memcpy_h2d(void* d, const void* s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
 inline int memcpy_d2h(void* d, const void* s, size_t n, stream_t) { memcpy(d, s, n); return 0; }
 inline int memcpy_d2d(void* d, const void* s, size_t n, stream_t) { memmove(d, s, n); return 0; }

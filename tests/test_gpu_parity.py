@@ -297,10 +297,25 @@ def test_full_width_48k_forward_against_oracle(hip):
     assert rel_l2(out.cpu(), ref) < P.NET_TOL
 
 
-@pytest.mark.parametrize("name", ["pc16k_full", "ode16k_full", "pc48k_full"])
+def test_full_width_48k_forward_at_the_benched_shape_against_oracle(hip):
+    """BASELINE configs[3] shape: one evaluation of ncsnpp_48k at [1,4,768,512] (4 s @48 kHz, 3.19 TFLOP) vs the CPU oracle."""
+    cfg = NO.NetCfg.for_variant("ncsnpp_48k")
+    net, Pm = P.make_backbone(cfg, hip)
+    x = torch.randn(1, 2, 768, 512, dtype=torch.complex64, generator=torch.Generator().manual_seed(23)) * 0.3
+    t = torch.tensor([0.21])
+    with torch.no_grad():
+        ref = NO.ncsnpp_forward(Pm, cfg, x, t)
+    out = net(x.to(hip), t.to(hip))
+    err = rel_l2(out.cpu(), ref)
+    print(f"ncsnpp_48k forward at [1,4,768,512]: rel_l2 vs oracle {err:.3e}")
+    assert err < P.NET_TOL
+
+
+@pytest.mark.parametrize("name", ["pc16k_full", "ode16k_full", "pc48k_full", "pc48k_T512"])
 def test_baseline_configuration_end_to_end_against_the_reference(hip, name):
     """BASELINE.json configs[0]/[1] (PC N=30), configs[2] (PF-ODE N=30) and configs[3] (48 kHz, PC N=50) at full width,
-    full length and full N: sampled spectrogram and enhanced waveform vs the reference's own run (tests/golden/*_full.npz)."""
+    full length and full N: sampled spectrogram and enhanced waveform vs the reference's own run (tests/golden/*_full.npz);
+    configs[3] additionally at the benched length (4 s: F=768 x T=512) with N=5 (what a CPU run of the reference affords)."""
     P.check_full_config(hip, name)
 
 

@@ -489,3 +489,107 @@ def test_bench_under_the_drivers_torch_distributed_run_line(emu):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["collective_backend"]["world_size"] == 2 and len(d["per_rank_utt_per_s"]) == 2
     assert d["weight_broadcast_ms"] > 0 and d["scaling"] == "weak"
+
+
+def test_assign_files_balances_by_padded_frames():
+    """--balance frames: longest-processing-time assignment by padded frame count; a partition of the file list that every rank
+    computes identically; --balance contiguous is the reference's split (model.py:212-223)."""
+    from sgmse_amd.enhancement import assign_files, padded_frames
+    from sgmse_amd.parallel import shard_range
+    rng = np.random.default_rng(3)
+    frames = [padded_frames(int(n), 128) for n in rng.lognormal(np.log(48000), 0.6, size=101)]
+    for world in (2, 3, 8):
+        parts = [assign_files(frames, r, world, "frames") for r in range(world)]
+        assert sorted(i for p in parts for i in p) == list(range(len(frames)))
+        loads = [sum(frames[i] for i in p) for p in parts]
+        assert max(loads) / (sum(loads) / world) <= 1.1, loads
+        cont = [assign_files(frames, r, world, "contiguous") for r in range(world)]
+        assert [(p[0], p[-1] + 1) for p in cont] == [shard_range(len(frames), r, world) for r in range(world)]
+    with pytest.raises(ValueError):
+        assign_files(frames, 0, 2, "random")
+
+
+def test_plan_batches_follows_the_cost_model():
+    from sgmse_amd.enhancement import plan_batches
+    frames = [512] * 70 + [576] * 3 + [640] * 2 + [1024]
+    idx = list(range(len(frames)))
+    plain = plan_batches(idx, frames, 32, ragged=False)
+    assert sorted(i for b in plain for i in b) == idx and all(len({frames[i] for i in b}) == 1 for b in plain)
+    rag = plan_batches(idx, frames, 32, ragged=True)
+    assert sorted(i for b in rag for i in b) == idx
+    assert sum(len(b) == 32 and len({frames[i] for i in b}) == 1 for b in rag) == 2       # full uniform batches stay uniform
+    assert any(len({frames[i] for i in b}) > 1 for b in rag)                                # the leftovers were pooled: 12 files, one batch
+    # a ragged batch priced above the small-batch penalty it avoids: the leftovers stay bucketed
+    assert all(len({frames[i] for i in b}) == 1 for b in plan_batches(idx, frames, 32, ragged=True, ragged_factor=3.0))
+
+
+_DIR_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch
+from sgmse_amd import _lib
+_lib.load_library({emu!r})
+from sgmse_amd import enhancement as E
+box = []
+orig = E.load_model
+def spy(*a):
+    m = orig(*a); box.append(m); return m
+E.load_model = spy
+import warnings
+warnings.simplefilter("ignore")
+n = E.main({argv!r})
+m = box[0]
+aff = m.score_affine(torch.linspace(1.0, 0.03, 5))
+torch.save(dict(n=n, affine=aff, hparams={{k: v for k, v in m.hparams.items() if k != 'data_module_cls'}},
+                w0=next(m.dnn.parameters()).detach().clone()), {out!r} + os.environ['RANK'])
+"""
+
+
+def test_three_rank_directory_job_balanced_by_frames_with_an_edm_checkpoint(emu, tmp_path):
+    """python -m sgmse_amd.enhancement under 3 ranks (gloo, emulator): rank 0 reads an ncsnpp_v2 checkpoint with the EDM
+    preconditioning (c_in / c_out / c_skip = 'edm', network_scaling '1/sigma'), the other ranks are built from the broadcast
+    hyper-parameters and must apply the SAME score wrapper (hparams used to drop those arguments); files of skewed
+    lengths are assigned by padded frame count (max / mean frames per rank <= 1.1) and the enhanced files equal the
+    single-process run bit for bit."""
+    from scipy.io import wavfile
+    from conftest import EMU_LIB
+    from sgmse_amd import enhancement as E
+    from sgmse_amd.model import ScoreModel
+    from sgmse_amd.data_module import SpecsDataModule
+    hp = dict(backbone="ncsnpp_v2", sde="ouve", nf=32, theta=1.5, sigma_min=0.05, sigma_max=0.5, N=30, t_eps=0.03,
+              loss_type="score_matching", c_in="edm", c_out="edm", c_skip="edm", network_scaling="1/sigma", sigma_data=0.2,
+              data_module_cls=SpecsDataModule, n_fft=510, hop_length=128, spec_factor=0.15, spec_abs_exponent=0.5)
+    torch.manual_seed(4)
+    src = ScoreModel(**hp)
+    assert ScoreModel(**src.hparams).c_in == "edm" and ScoreModel(**src.hparams).network_scaling == "1/sigma"
+    ckpt = tmp_path / "m.ckpt"
+    torch.save({"state_dict": {"dnn." + k: v.clone() for k, v in src.dnn.state_dict().items()}, "hyper_parameters": hp}, ckpt)
+    noisy = tmp_path / "noisy"
+    noisy.mkdir()
+    rng = torch.Generator().manual_seed(5)
+    lengths = [30000, 5000, 5000, 5000, 9000, 5000, 5000]          # padded frames 256, 64, 64, 64, 128, 64, 64 (reflection pad < frames)
+    for i, L in enumerate(lengths):
+        wavfile.write(str(noisy / f"f{i}.wav"), 16000, (0.1 * torch.randn(L, generator=rng)).numpy())
+    frames = [E.padded_frames(L, 128) for L in lengths]
+    loads = [sum(frames[i] for i in E.assign_files(frames, r, 3, "frames")) for r in range(3)]
+    assert max(loads) / (sum(loads) / 3) <= 1.1 and max(sum(frames[i] for i in E.assign_files(frames, r, 3, "contiguous")) for r in range(3)) > max(loads)
+    base = ["--test_dir", str(noisy), "--ckpt", str(ckpt), "--device", "cpu", "--N", "1", "--corrector", "none", "--seed", "7", "--batch_size", "4"]
+    script = tmp_path / "worker.py"
+    out = str(tmp_path / "rank")
+    script.write_text(_DIR_WORKER.format(root=ROOT, emu=EMU_LIB, out=out, argv=base + ["--enhanced_dir", str(tmp_path / "o3"), "--balance", "frames"]))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="3", SGMSE_EMU_THREADS="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(3)]
+    logs = [p.communicate(timeout=1500)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    res = [torch.load(out + str(r), weights_only=False) for r in range(3)]
+    assert sum(r["n"] for r in res) == len(lengths)
+    for r in res[1:]:                                              # same wrapper, same weights on every rank
+        assert r["hparams"] == res[0]["hparams"] and torch.equal(r["w0"], res[0]["w0"])
+        assert all(torch.equal(a, b) for a, b in zip(r["affine"], res[0]["affine"]))
+    assert res[0]["hparams"]["c_in"] == "edm" and not torch.equal(res[0]["affine"][0], torch.ones(5))
+    with pytest.warns(UserWarning):                                # single process, contiguous, other batches: the same files
+        assert E.main(base + ["--enhanced_dir", str(tmp_path / "o1")]) == len(lengths)
+    for i in range(len(lengths)):
+        a, b = wavfile.read(str(tmp_path / "o1" / f"f{i}.wav"))[1], wavfile.read(str(tmp_path / "o3" / f"f{i}.wav"))[1]
+        assert np.array_equal(a, b) and np.isfinite(a).all() and np.abs(a).max() > 0, i
