@@ -123,13 +123,16 @@ inline void launch_conv3x3_split_t(const ConvArgs& a, dim3 grid, drt::stream_t s
   if (act) DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1>), grid, dim3(256), st, a);
   else DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 0>), grid, dim3(256), st, a);
 }
+// rows per GroupNorm-statistics sub-tile the split kernels emit for this layer (ConvArgs::stats_rows): 4, except the thin shape
+// (two rows per wave; its layers emit no statistics in the network)
+inline int conv_split_stats_rows(int ks, int Cout) { return (ks == 3 && Cout <= 32) ? 1 : 4; }
 inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t st, bool rows4 = false, int abl = 0, int ksplit = 1) {
   const int tiles = a.B * ((a.H + 7) / 8) * ((a.W + 31) / 32);
   if (ks == 3 && a.Cout > 32 && rows4 && a.kchunk_stages > 0 && mode == 2) {     // chunked accumulation / split-K (coarse levels)
     const dim3 grid(a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32), a.Cout / 128, ksplit);
     if (a.in_scale && a.in_act) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2, 1, 0, 0, 0, 1>), grid, dim3(256), st, a);
     else DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2, 0, 0, 0, 0, 1>), grid, dim3(256), st, a);
-    if (ksplit > 1) DRT_LAUNCH((conv_splitk_reduce_kernel<3, 4, 1, 4>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
+    if (ksplit > 1) DRT_LAUNCH((conv_splitk_reduce_kernel<3, 4, 1, 4, true>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
     return;
   }
   if (ks == 3 && a.Cout > 32 && rows4) {

@@ -240,7 +240,8 @@ class Arena {
 };
 
 // st: [B][C][nsub][2] GroupNorm partial sums; amax: [B] upper bounds of |x| per utterance (null: unknown range)
-struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; float* st = nullptr; int nsub = 0; float* amax = nullptr; };
+// srows: image rows per statistics sub-tile (1: the fp32 kernels, 4: the split kernels; ConvArgs::stats_rows)
+struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; float* st = nullptr; int nsub = 0; float* amax = nullptr; int srows = 1; };
 
 struct ConvW {            // one convolution's parameters on the device
   const float* oihw = nullptr;   // [cout][cin][ks][ks] (for NIN: transposed copy)
@@ -595,7 +596,7 @@ class Engine {
     if (C2) DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C2), dim3(256), stream_, x2, (const float*)nullptr, C2, 0, HW, stats2, Rag{nullptr, nullptr, nullptr}, 0);
     const int G = std::min(C / 4, 32);
     DRT_LAUNCH(gn_finalize_kernel, dim3(G, B), dim3(256), stream_, (const float*)stats, C1, 1, (const float*)stats2, C2, 1, gamma, beta, G,
-               HW, 1e-6f, sc, sh, Rag{nullptr, nullptr, nullptr}, 0, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+               HW, 1e-6f, sc, sh, Rag{nullptr, nullptr, nullptr}, 0, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 1, 1);
     DRT_LAUNCH(gn_apply_kernel, dim3((HW + 1023) / 1024, B * C), dim3(256), stream_, x, x2, C1, C2, HW, (const float*)sc,
                (const float*)sh, act, out);
     SG_CHECK(drt::stream_sync(stream_));
@@ -1110,12 +1111,13 @@ class Engine {
     if (bound) *bound = bslot;
     const float* st[2] = {a.st, b ? b->st : nullptr};
     int nsub[2] = {a.nsub, b ? b->nsub : 0};
+    int srows[2] = {a.srows, b ? b->srows : 1};
     float* tmp[2] = {nullptr, nullptr};
     const Tensor* src[2] = {&a, b};
     for (int k = 0; k < 2; ++k) {
       if (!src[k] || st[k]) continue;
       tmp[k] = arena_.alloc((size_t)B_ * src[k]->C * 2);
-      st[k] = tmp[k]; nsub[k] = 1;
+      st[k] = tmp[k]; nsub[k] = 1; srows[k] = 1;
       if (!dry_) {
         tock();
         DRT_LAUNCH(gn_chan_stats_kernel, dim3(B_ * src[k]->C), dim3(256), stream_, (const float*)src[k]->p, (const float*)nullptr,
@@ -1130,7 +1132,7 @@ class Engine {
       tock();
       const int G = std::min(C / 4, 32);
       DRT_LAUNCH(gn_finalize_kernel, dim3(G, B_), dim3(256), stream_, st[0], a.C, nsub[0], st[1], b ? b->C : 0, nsub[1], gamma, beta, G,
-                 HW, 1e-6f, *sc, *sh, rag_of(a.H), a.H, (const float*)a.amax, (const float*)(b ? b->amax : nullptr), bslot);
+                 HW, 1e-6f, *sc, *sh, rag_of(a.H), a.H, (const float*)a.amax, (const float*)(b ? b->amax : nullptr), bslot, srows[0], srows[1]);
       if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "gn_finalize C=%d nsub=%d @%dx%dx%d", C, nsub[0], B_, a.H, a.W);
       tick(TC_GN, 8.0 * B_ * ((double)a.C * nsub[0] + (b ? (double)b->C * nsub[1] : 0.0)), 1);
     }
@@ -1222,7 +1224,11 @@ class Engine {
       }
     }
     if (emit_stats && use_mfma && fuse_gn_stats_) {
-      o.nsub = conv_plan_nsub(a.H, a.W);
+      // the split kernels emit one partial pair per 4 image rows, the fp32 kernels one per row (ConvArgs::stats_rows): a property
+      // of the kernel family, which is a property of the layer and level
+      o.srows = use_split ? conv_split_stats_rows(w.ks, w.cout) : 1;
+      SG_REQUIRE(o.srows == 1 || !ragged() || a.H % 4 == 0, "ragged batch: 4-row statistics sub-tiles need H % 4 == 0");
+      o.nsub = conv_plan_nsub(a.H, a.W, o.srows);
       o.st = arena_.alloc((size_t)B_ * w.cout * o.nsub * 2);
     } else if (emit_stats && fuse_gn_stats_) {
       // direct kernel: one statistics pass right behind it, kept with the tensor -- these outputs (entry conv, Combine)
@@ -1233,7 +1239,7 @@ class Engine {
     o.amax = next_amax();
     if (dry_) { if (partial) arena_.release(partial); return o; }
     ConvArgs ca{};
-    ca.stats_out = o.st; ca.stats_nsub = o.nsub;
+    ca.stats_out = o.st; ca.stats_nsub = o.nsub; ca.stats_rows = o.srows;
     ca.amax_out = o.amax;
     ca.src1 = a.p; ca.src2 = b ? b->p : nullptr; ca.C1 = a.C; ca.C2 = b ? b->C : 0;
     ca.bias = bias; ca.bias2 = bias2; ca.bias2_bstride = ctl.bias_bstride; ca.bias2_sstride = ctl.bias_sstride;

@@ -55,6 +55,11 @@ struct ConvArgs {
   // on which tile shape a launch used.  Deterministic (no atomics); stats_nsub = H * ceil(W/32).
   float* stats_out;
   int stats_nsub;
+  // rows per statistics sub-tile: 1 (the fp32 MFMA kernels, whose tile shapes go down to one row per wave) or 4 (the split-operand
+  // kernels: every shape gives a wave 4 or 8 consecutive rows, so a wave sums its per-row results over 4 rows before storing --
+  // a quarter of the partials to write and to read back; sub-tile index (y / 4) * ceil(W/32) + x/32, stats_nsub = ceil(H/4) *
+  // ceil(W/32)).  Decided by the kernel FAMILY, which is decided per layer and level: still independent of tile shape and batch.
+  int stats_rows;
   // optional per-utterance max |stored output| ([B][kAmaxSpread]: atomic max, order-independent and therefore
   // deterministic, spread over kAmaxSpread words per utterance so that the atomics of a launch do not serialise on one
   // address; zeroed by the engine before the forward): the range bound from which an fp16x2 consumer of this tensor picks
@@ -119,8 +124,9 @@ __device__ __forceinline__ bool conv_ragged_adjust(ConvArgs& p, int b, int tx) {
   if (p.sc_src2) p.sc_src2 += d * p.sc_C2;
   if (p.partial) p.partial += d * p.Cout;
   if (p.stats_out) {            // statistics sub-tiles packed per utterance too: [soff[b] .. ) x Cout pairs, H * ceil(W_b / 32) per channel
-    const int nsub = p.H * ((Wb + 31) >> 5);
-    p.stats_out += (p.rag_soff[b] - (long long)b * nsub) * p.Cout * 2;
+    const int rps = p.stats_rows == 4 ? 4 : 1;          // (4-row sub-tiles: H % 4 == 0 in every ragged launch, so the prefix divides)
+    const int nsub = (p.H / rps) * ((Wb + 31) >> 5);
+    p.stats_out += (p.rag_soff[b] / rps - (long long)b * nsub) * p.Cout * 2;
     p.stats_nsub = nsub;
   }
   return true;
@@ -217,7 +223,7 @@ __device__ __forceinline__ void conv_acc_init(const ConvArgs& p, int b, int co_b
 // 16, 8, 7 (mirror), 1 a lane owns ONE of the 16 registers summed over 16 lanes, and the final ^2 step completes it.
 // The order of the additions is a function of (row, segment) only -- not of the tile shape, wave or workgroup -- so the
 // statistics, and everything computed from them, do not depend on which tile shape a launch used.
-template <class T, int FC, int FP, int WC, bool GUARD, int ABL, bool PRE, bool RES>
+template <class T, int FC, int FP, int WC, bool GUARD, int ABL, bool PRE, bool RES, bool STAT4>
 __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&acc)[FC][FP], int b, int co_blk, int tx, int ty,
                                                     int tiles_x, int wc, int wp, int l31, int kh, float as) {
   constexpr int CO_T = T::CO_T, ROWS = T::ROWS;
@@ -267,6 +273,7 @@ __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&
     }
     // residual rows are loaded PF - 1 fragment rows ahead of their use (independent loads; issued one by one behind their
     // dependent add + store the residual read cost 11 % of the fp32 kernel, profiles/r01_conv_ablation.txt)
+    float st1 = 0.f, st2 = 0.f;     // STAT4: this lane's {sum, sum of squares} over the rows of the current 4-row sub-tile
     float rr[PF][16];
     auto load_res = [&](int j, int slot) {
       const bool rok = !GUARD || (yb + j < H && xok);
@@ -324,9 +331,19 @@ __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&
         const int co = co_l + (r & 3) + 8 * (r >> 2);
         // lanes l and l ^ 2 hold the same sums and both store them (same address, same value): predicating one of them
         // away costs an exec-mask region per row, which the compiler gathers at the end of the epilogue with the sums spilled
-        if (!GUARD || co < p.Cout) {
-          float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)y * tiles_x + tx) * 2;
-          so[0] = e1; so[1] = e2;
+        if constexpr (STAT4) {
+          // rows in image order, ((r0 + r1) + r2) + r3 of the per-row butterfly results: the same in the 4-row and 8-row shapes
+          st1 = (j & 3) == 0 ? e1 : st1 + e1;
+          st2 = (j & 3) == 0 ? e2 : st2 + e2;
+          if (((j & 3) == 3 || (GUARD && y + 1 >= H)) && (!GUARD || co < p.Cout)) {
+            float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)(y >> 2) * tiles_x + tx) * 2;
+            so[0] = st1; so[1] = st2;
+          }
+        } else {
+          if (!GUARD || co < p.Cout) {
+            float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)y * tiles_x + tx) * 2;
+            so[0] = e1; so[1] = e2;
+          }
         }
       }
     }
@@ -341,20 +358,22 @@ __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&
 // global stores, bit 1 skip the residual read, bit 7 residual rows loaded right before their use, bit 8 non-temporal
 // cache policy on the residual loads and output stores
 // PRE: the kernel initialised its accumulators with (bias + bias2) / as (conv_acc_init), the epilogue adds no bias
-template <class T, int FC, int FP, int WC, int ABL = 0, bool PRE = false>
+// STAT4: GroupNorm partials per 4 image rows (ConvArgs::stats_rows == 4; needs FP % 4 == 0: a wave's rows are whole sub-tiles)
+template <class T, int FC, int FP, int WC, int ABL = 0, bool PRE = false, bool STAT4 = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[FC][FP], int b, int co_blk, int tx, int ty,
                                               int tiles_x, int wc, int wp, int l31, int kh, float as_mul = 1.0f) {
+  static_assert(!STAT4 || FP % 4 == 0, "4-row statistics sub-tiles need 4 or 8 rows per wave");
   const float as = (p.acc_scale ? *p.acc_scale : 1.0f) * as_mul;     // exact powers of two (or 1)
   // wave-uniform: are this wave's channels, rows and columns all inside the tensor?
   const bool inside = (co_blk * T::CO_T + (wc * FC + FC) * 32 <= p.Cout) && (ty * T::ROWS + wp * FP + FP <= p.H) && (tx * 32 + 32 <= p.W);
   const bool res = p.res != nullptr && !(ABL & 2);
   float vmax;
   if (inside) {
-    if (res) vmax = conv_epilogue_body<T, FC, FP, WC, false, ABL, PRE, true>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
-    else vmax = conv_epilogue_body<T, FC, FP, WC, false, ABL, PRE, false>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
+    if (res) vmax = conv_epilogue_body<T, FC, FP, WC, false, ABL, PRE, true, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
+    else vmax = conv_epilogue_body<T, FC, FP, WC, false, ABL, PRE, false, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
   } else {
-    if (res) vmax = conv_epilogue_body<T, FC, FP, WC, true, ABL, PRE, true>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
-    else vmax = conv_epilogue_body<T, FC, FP, WC, true, ABL, PRE, false>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
+    if (res) vmax = conv_epilogue_body<T, FC, FP, WC, true, ABL, PRE, true, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
+    else vmax = conv_epilogue_body<T, FC, FP, WC, true, ABL, PRE, false, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
   }
   if (p.amax_out) {      // wave-uniform
 #pragma unroll
@@ -658,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
 // Second half of a split-K convolution (ConvArgs::kchunk_stages): sums the chunks' partial sums in chunk order into the
 // accumulator layout of the producing tile shape and runs the ordinary epilogue (bias, time embedding, residual, scale,
 // GroupNorm partials, range bound).  grid = (tiles, output-channel blocks) of the tile shape <KS, WC, FC, FP>.
-template <int KS, int WC, int FC, int FP>
+template <int KS, int WC, int FC, int FP, bool STAT4 = false>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int nchunks) {
   using T = ConvTile<KS, WC, FC, FP, 1>;
   constexpr int ROWS = T::ROWS, CO_T = T::CO_T;
@@ -718,7 +737,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
   // chunks of the fp16x2 kernel carry its per-utterance input scale (ConvArgs::xbound); the fp32 kernels' chunks carry none
   float as_mul = 1.0f;
   if (p.xbound) as_mul = 1.0f / h2_weight_scale(amax_read(p.xbound, b));
-  conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as_mul);
+  conv_epilogue<T, FC, FP, WC, 0, false, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as_mul);
 }
 
 // Direct (VALU) convolution: one thread per output pixel, CG output channels per thread.
@@ -831,7 +850,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs p) {
 // Which MFMA tile a layer uses.  co_t in {32,64,128}; rows in {8,4}.
 struct ConvPlan { int co_t; int rows; bool mfma; };
 inline int conv_plan_wp(int co_t) { return co_t == 32 ? 4 : 2; }            // pixel-waves per workgroup (ConvTile::WP)
-inline int conv_plan_nsub(int H, int W) { return H * ((W + 31) / 32); }     // statistics sub-tiles per image (tile-independent)
+inline int conv_plan_nsub(int H, int W, int rows = 1) { return ((H + rows - 1) / rows) * ((W + 31) / 32); }   // statistics sub-tiles per image (tile-independent)
 
 inline ConvPlan choose_conv_plan(int ks, int cin, int cout, int H, int W) {
   ConvPlan pl{0, 0, false};

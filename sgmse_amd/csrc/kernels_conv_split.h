@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   // works instead of after the tap; the split runs on every second element (packed conversions)
   u32x4 pk[NS];
   float ev = 0.f;
-  auto stage_elem = [&](int i, int e, int c0) {
-    const float o = produce(rin[i][e], c0 + 8 * it_g[i] + e);
+  auto stage_elem = [&](int i, int e, int c0, const float (&raw)[C::NIT][8]) {
+    const float o = produce(raw[i][e], c0 + 8 * it_g[i] + e);
     if ((e & 1) == 0) { ev = o; return; }
     uint32_t d[NS];
     S::split2(ev, o, d);
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   // MFMAs of fragment j (order pinned with sched_barrier: left alone, the compiler sinks every LDS read to just in front
   // of its first use and waits lgkmcnt(0) for each).
   u32x4 bq[2][NS];
-  auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[FCW][NS], int item, int c0n, u32x4* nxt) {
+  auto compute_tap = [&](const u32x4* sbuf, int tap, const u32x4 (&a)[FCW][NS], int item, int c0n, u32x4* nxt, const float (&raw)[C::NIT][8]) {
     const int dy = tap / 3, dx = tap - 3 * dy;
     const u32x4* sb = sbuf + b_lane + (dy * C::TCOLS + dx) * PX_V;
     if constexpr (!(ABL & 16)) {
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
         for (int i = 0; i < FCW; ++i) acc[i][j] = S::mfma(a[i][S::pa(k)], bq[j & 1][S::pb(k)], acc[i][j]);
       if (item >= 0) {
 #pragma unroll
-        for (int e = 0; e < EPJ; ++e) stage_elem(item, j * EPJ + e, c0n);
+        for (int e = 0; e < EPJ; ++e) stage_elem(item, j * EPJ + e, c0n, raw);
         if (j == FPW - 1) flush_item(item, nxt);
       }
       __builtin_amdgcn_sched_barrier(SGMSE_SPLIT_FENCE);
@@ -484,13 +484,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     for (int st = 0; st < nsts; st += 2) {
       load_asc(st, asc);
       if (st + 2 < nsts) load_sc((st + 2) * C::KC, rin);
-      compute_tap(s_in0, 4, asc, -1, 0, s_in1);
+      compute_tap(s_in0, 4, asc, -1, 0, s_in1, rin);
       if (st + 1 < nsts) store_sc(rsc, s_in1);
       __syncthreads();
       if (st + 1 < nsts) {
         load_asc(st + 1, asc);
         if (st + 3 < nsts) load_sc((st + 3) * C::KC, rsc);
-        compute_tap(s_in1, 4, asc, -1, 0, s_in0);
+        compute_tap(s_in1, 4, asc, -1, 0, s_in0, rin);
         if (st + 2 < nsts) store_sc(rin, s_in0);
         __syncthreads();
       }
@@ -533,6 +533,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   unsigned long long tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // ABL 64: time per tap position and at the stage barrier (wave 0)
   // (a ring holding a whole stage -- 9 sets, 8 taps ahead -- for the 4-row shape, whose taps have half the MFMAs to cover a
   // load, measured no gain at batch 1 and costs the third workgroup per CU: profiles/r02 gpu_r02_coarse.sh)
+  if constexpr (THIN && !ABL) {
+    // ---- thin shape (C -> 4 pyramid convolutions): a tap is only 6 MFMAs per wave (~190 cycles), and vmcnt retires in order: with
+    // the fragment ring above, the wait for a fragment loaded two taps ahead also waits for the raw HBM loads of the next stage
+    // issued in front of it, ~400 cycles after their issue, every stage (2.0 ms per evaluation at batch 32 for 0.6 ms of HBM
+    // reads, profiles/r02_prof_dump_b32_final.txt).  Here the fragments of a WHOLE stage live in registers (9 x 8 VGPRs): the
+    // fragment of tap t is reloaded for the next stage right after tap t's MFMAs (a full stage of cover), and the raw inputs run
+    // TWO stages ahead in two register sets, an item reloaded as soon as the producer has consumed it (two stages of cover, ten
+    // taps before the next younger fragment is waited for).  Same K order, same arithmetic: bit-identical to the ring loop.
+    static_assert(FCW == 1, "thin shape");
+    float rin2[C::NIT][8];
+    u32x4 af[9][FCW][NS];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) load_a(0, t, af[t]);
+    auto load_raw = [&](int i, int c0, float (&dst)[C::NIT][8]) {
+      const bool first = c0 < p.C1;
+      const float* base = first ? p.src1 + ((size_t)b * p.C1 + c0) * HW : p.src2 + ((size_t)b * p.C2 + (c0 - p.C1)) * HW;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        dst[i][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (size_t)e * HW) + it_boff[i]);
+    };
+    auto clampst = [&](int st) { return st < nst ? st : nst - 1; };      // past the end: re-stage the last stage (never read)
+#pragma unroll
+    for (int i = 0; i < C::NIT; ++i) { load_raw(i, clampst(1) * C::KC, rin); load_raw(i, clampst(2) * C::KC, rin2); }
+    auto thin_stage = [&](int st, const u32x4* cur, u32x4* nxt, float (&raw)[C::NIT][8]) {
+      const int stn = clampst(st + 1), str = clampst(st + 3);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int item = (tap >= 4 && (tap & 1) == 0 && (tap - 4) / 2 < C::NIT) ? (tap - 4) / 2 : -1;
+        compute_tap(cur, tap, af[tap], item, stn * C::KC, nxt, raw);
+        load_a(stn, tap, af[tap]);
+        if (item >= 0) load_raw(item, str * C::KC, raw);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    };
+#pragma unroll 1
+    for (int st = 0; st < nst; st += 2) {
+      thin_stage(st, s_in0, s_in1, rin);
+      if (st + 1 < nst) thin_stage(st + 1, s_in1, s_in0, rin2);
+    }
+    conv_epilogue<T, FCW, FPW, WCW, 0, true, false>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
+    return;
+  }
   constexpr int AR = 3, AD = AR - 1;
   u32x4 ar[AR][FCW][NS];
 #pragma unroll
@@ -565,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       int item = (tap >= 4 && (tap & 1) == 0 && (tap - 4) / 2 < C::NIT) ? (tap - 4) / 2 : -1;   // taps 4, 6, 8: items 0, 1, 2
       if constexpr (ABL & 8) item = -1;
-      compute_tap(cur, tap, ar[tap % AR], item, stn * C::KC, nxt);
+      compute_tap(cur, tap, ar[tap % AR], item, stn * C::KC, nxt, rin);
       if constexpr (ABL & 64) { __builtin_amdgcn_sched_barrier(0); tsum[tap] += drt_clock() - tc0; }
     }
     if constexpr (ABL & 64) {
@@ -609,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   }
 
   if constexpr (ABL & 64) { if (trace) trace[3] = drt_clock(); }
-  conv_epilogue<T, FCW, FPW, WCW, ABL & (3 | 128 | 256), !CHK>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
+  conv_epilogue<T, FCW, FPW, WCW, ABL & (3 | 128 | 256), !CHK, FPW % 4 == 0>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
   if constexpr (ABL & 64) { if (trace) trace[4] = drt_clock(); }
 }
 
@@ -772,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
       for (int e = 0; e < 8; ++e) rinA[i][e] = rinB[i][e];
   }
 
-  conv_epilogue<T, 1, 8, 4>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg, 1.0f / xs);
+  conv_epilogue<T, 1, 8, 4, 0, false, true>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg, 1.0f / xs);
 }
 
 }  // namespace sgmse

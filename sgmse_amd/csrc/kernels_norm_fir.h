@@ -75,7 +75,7 @@ __device__ __forceinline__ void gn_sum_pairs(const float* base, int n, double& s
 // stream them coalesced (fixed thread -> element map and a fixed fp64 tree: deterministic), then thread c < cpg writes the
 // folded coefficients of channel g*cpg + c.
 // Ragged launch (rag.w): utterance b has H * rag.w[b] pixels per plane; a source whose partials come from a convolution
-// epilogue (nsub > 1) holds them packed per utterance -- H * ceil(w / 32) sub-tiles per channel from sub-tile rag.soff[b] on,
+// epilogue (nsub > 1) holds them packed per utterance -- (H / rps) * ceil(w / 32) sub-tiles per channel from sub-tile rag.soff[b] / rps on,
 // exactly the layout of the utterance's own launch; gn_chan_stats sources (nsub == 1) are one pair per (b, c) either way.
 // Range bound for an fp16x2 consumer (bound_out, [B][kAmaxSpread], zeroed by the engine; null: not wanted): an upper bound of
 // |x * scale + shift| -- and with it of its SiLU, |silu(t)| <= |t| -- over the utterance, from the utterance's own data:
@@ -85,17 +85,18 @@ __device__ __forceinline__ void gn_sum_pairs(const float* base, int n, double& s
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* st1, int C1, int nsub1, const float* st2, int C2, int nsub2,
                                                           const float* gamma, const float* beta, int G, int HW, float eps,
                                                           float* scale, float* shift, Rag rag, int H,
-                                                          const float* amax1, const float* amax2, float* bound_out) {
+                                                          const float* amax1, const float* amax2, float* bound_out, int rps1, int rps2) {
   __shared__ double s_s[256];
   __shared__ double s_q[256];
   const int g = blockIdx.x, b = blockIdx.y, C = C1 + C2, cpg = C / G;
   const int c_lo = g * cpg, c_hi = c_lo + cpg;
   size_t sb1 = (size_t)b * nsub1, sb2 = (size_t)b * nsub2;       // first sub-tile of utterance b, per channel-set
   if (rag.w) {
+    // rps: image rows per statistics sub-tile of the source (1, or 4 for tensors the split kernels produced; H % 4 == 0 then)
     const int w = rag.w[b], ns = H * ((w + 31) >> 5);
     HW = H * w;
-    if (nsub1 > 1) { nsub1 = ns; sb1 = (size_t)rag.soff[b]; }
-    if (nsub2 > 1) { nsub2 = ns; sb2 = (size_t)rag.soff[b]; }
+    if (nsub1 > 1) { nsub1 = ns / rps1; sb1 = (size_t)(rag.soff[b] / rps1); }
+    if (nsub2 > 1) { nsub2 = ns / rps2; sb2 = (size_t)(rag.soff[b] / rps2); }
   }
   double s = 0.0, q = 0.0;
   // source 1 covers channels [c_lo, min(c_hi, C1)), source 2 the rest (a group may straddle the concat boundary)
@@ -317,6 +318,13 @@ __device__ __forceinline__ void fir_stage_tile(const FirArgs& p, const float* pl
   }
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs by their linear id, and every XCD has its own L2: with the plain map the
+// four tiles of a tile row (and the rows above / below) sit on different XCDs, so every halo row and halo column line is fetched
+// from HBM once per tile -- fir_down2_tiled fetched 1.54 x its input (profiles/r02_hbm_traffic_conv3x3_split_h2_b8.json).  This
+// map hands XCD k the k-th contiguous eighth of a plane's tiles (whole tile rows), so neighbours share their halo lines in L2.
+// A bijection of the tile index: results unchanged.
+__device__ __forceinline__ int fir_xcd_tile(int t, int nt) { return (nt & 7) == 0 ? (t & 7) * (nt >> 3) + (t >> 3) : t; }
+
 // grid = (ceil(Wo/64) * ceil(Ho/8), BC); thread -> output column ox (64) and the output row pair 2*rp, 2*rp+1
 __device__ __forceinline__ void fir_down2_tile_emit(const float* s, int rp, int oxl, float* out, int Wo, bool row1) {
   using TT = FirTileDown;
@@ -337,7 +345,8 @@ __global__ __launch_bounds__(256) void fir_down2_tiled_kernel(FirArgs p) {
   __shared__ float sx[TT::IR * TT::RS];
   __shared__ float sr[TT::IR * TT::RS];
   const int tiles_x = (p.W / 2 + TT::TO_W - 1) / TT::TO_W;          // grid layout (ragged launches: of the widest utterance)
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int tile = fir_xcd_tile((int)blockIdx.x, (int)gridDim.x);
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int bc = blockIdx.y;
   if (p.rag.w) { fir_ragged_adjust(p, bc, false); if (tx * TT::TO_W >= p.W / 2) return; }
   const int Ho = p.H / 2, Wo = p.W / 2;
@@ -382,7 +391,8 @@ __global__ __launch_bounds__(256) void fir_up2_tiled_kernel(FirArgs p) {
   __shared__ float sx[TT::IR * TT::RS];
   __shared__ float sr[TT::IR * TT::RS];
   const int tiles_x = (p.W + TT::TI_W - 1) / TT::TI_W;              // grid layout (ragged launches: of the widest utterance)
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int tile = fir_xcd_tile((int)blockIdx.x, (int)gridDim.x);
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int bc = blockIdx.y;
   if (p.rag.w) { fir_ragged_adjust(p, bc, true); if (tx * TT::TI_W >= p.W) return; }
   const int H = p.H, W = p.W;
