@@ -180,6 +180,9 @@ int sgmse_set_frames(sgmse_ctx* ctx, const int* frames, int n);
 /* how many times this context captured + instantiated a sampler step as a hipGraph (a run over many batches of one shape and
  * sampler configuration captures once: the Philox seed is device data, not a graph parameter) */
 int sgmse_graph_captures(sgmse_ctx* ctx, int* out);
+/* how many times a captured step was brought up to date IN PLACE (hipGraphExecUpdate: same launch sequence, other arguments --
+ * a new ragged batch composition, a new batch size of the same kernel sequence) instead of being instantiated anew */
+int sgmse_graph_updates(sgmse_ctx* ctx, int* out);
 
 #ifdef __cplusplus
 }

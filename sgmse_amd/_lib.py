@@ -70,6 +70,7 @@ _SIGS = {
     "sgmse_bench_conv": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "sgmse_arena_bytes": (_I, [_P, C.POINTER(_LL)]),
     "sgmse_graph_captures": (_I, [_P, C.POINTER(_I)]),
+    "sgmse_graph_updates": (_I, [_P, C.POINTER(_I)]),
     "sgmse_set_noise_streams": (_I, [_P, C.POINTER(C.c_ulonglong), _I]),
     "sgmse_set_frames": (_I, [_P, C.POINTER(_I), _I]),
 }
@@ -385,16 +386,25 @@ class Context:
         self._keep["sb"] = (noise, keep, aff)
         return out, nfe.value
 
-    def profile_forward(self, xy: torch.Tensor, t: torch.Tensor):
-        xy = check_tensor(xy, "x", torch.complex64, self.device)
+    def profile_forward(self, xy, t: torch.Tensor):
+        """Per-kernel-class HIP-event timing of ONE network evaluation (eager).  xy: complex64 [B,2,F,T], or a list of [2,F,T_b]
+        (a ragged batch, as forward_ragged takes it)."""
         t = check_tensor(t, "t", torch.float32, self.device)
-        B, _, F_, T = xy.shape
-        out = torch.empty((B, 1, F_, T), dtype=torch.complex64, device=self.device)
+        frames = []
+        if isinstance(xy, (list, tuple)):
+            frames, F_ = _ragged_geometry(xy, 2, "x")
+            B, T = len(xy), max(frames)
+            xy = torch.cat([check_tensor(x, "x", torch.complex64, self.device).reshape(-1) for x in xy])
+            out = torch.empty(F_ * sum(frames), dtype=torch.complex64, device=self.device)
+        else:
+            xy = check_tensor(xy, "x", torch.complex64, self.device)
+            B, _, F_, T = xy.shape
+            out = torch.empty((B, 1, F_, T), dtype=torch.complex64, device=self.device)
         ms = (_F * SGMSE_NCLASS)()
         fl = (C.c_double * SGMSE_NCLASS)()
         nl = (_I * SGMSE_NCLASS)()
         self.use_current_stream()
-        self.set_frames([])
+        self.set_frames(frames)
         self.check(self.lib.sgmse_profile_forward(self.h, xy.data_ptr(), t.data_ptr(), out.data_ptr(), B, F_, T, ms, fl, nl))
         return {n: {"ms": ms[i], "work": fl[i], "unit": CLASS_WORK_UNIT[i], "launches": nl[i]}
                 for i, n in enumerate(CLASS_NAMES)}, out
@@ -448,6 +458,12 @@ class Context:
         """Number of hipGraph captures (+ instantiations) of a sampler step this context has done."""
         out = _I(0)
         self.check(self.lib.sgmse_graph_captures(self.h, C.byref(out)))
+        return out.value
+
+    def graph_updates(self) -> int:
+        """Number of times a captured step was updated in place (hipGraphExecUpdate) instead of being instantiated anew."""
+        out = _I(0)
+        self.check(self.lib.sgmse_graph_updates(self.h, C.byref(out)))
         return out.value
 
     def arena_bytes(self) -> int:

@@ -215,4 +215,9 @@ int sgmse_graph_captures(sgmse_ctx* ctx, int* out) {
   return sg_guard(ctx, [&](sgmse::Engine& e) { *out = e.graph_captures(); });
 }
 
+int sgmse_graph_updates(sgmse_ctx* ctx, int* out) {
+  SG_ARG(ctx, out != nullptr, "out is null");
+  return sg_guard(ctx, [&](sgmse::Engine& e) { *out = e.graph_updates(); });
+}
+
 }  // extern "C"

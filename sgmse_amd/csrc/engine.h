@@ -286,7 +286,7 @@ class Engine {
   ~Engine() {
     for (void* p : owned_) drt::free_dev(p);
     for (void* p : wowned_) drt::free_dev(p);
-    if (graph_valid_) drt::graph_destroy(&graph_);
+    if (graph_valid_ || graph_stale_) drt::graph_destroy(&graph_);
     if (hstage_) drt::free_host(hstage_);
     if (hstage_ev_init_) drt::event_destroy(&hstage_ev_);
   }
@@ -337,6 +337,7 @@ class Engine {
     const float* bias_table; int bias_bstride, bias_sstride; const int* step_ptr;
     const float* tvals; int t_bstride, t_sstride; float sign;
     const float* coef = nullptr; int coef_bstride = 0, coef_sstride = 0;   // score-wrapper rows {gamma, alpha, beta, -} or null
+    const int* bias_step = nullptr;   // step counter the convolutions read for their bias row (null: row 0 / per-utterance rows)
     int y_plane = 0;     // ragged launches: y of utterance b lies y_plane * F * T_b elements behind its x-relative position (entry_kernel)
   };
 
@@ -436,11 +437,8 @@ class Engine {
     if (want_graph) {
       if (!graph_valid_ || !(key == graph_key_)) {
         invalidate_graph();
-        SG_CHECK(drt::stream_sync(stream_));
-        SG_CHECK(drt::graph_begin_capture(stream_));
-        step_body();
-        SG_CHECK(drt::graph_end_capture(stream_, &graph_));
-        graph_valid_ = true; graph_key_ = key; ++graph_captures_;
+        capture_step(step_body);
+        graph_key_ = key;
       }
       for (int i = 0; i < sc.N; ++i) SG_CHECK(drt::graph_launch(&graph_, stream_));
     } else {
@@ -496,11 +494,8 @@ class Engine {
     if (use_graph && drt::graphs_supported()) {
       if (!graph_valid_ || !(key == graph_key_)) {
         invalidate_graph();
-        SG_CHECK(drt::stream_sync(stream_));
-        SG_CHECK(drt::graph_begin_capture(stream_));
-        step_body();
-        SG_CHECK(drt::graph_end_capture(stream_, &graph_));
-        graph_valid_ = true; graph_key_ = key; ++graph_captures_;
+        capture_step(step_body);
+        graph_key_ = key;
       }
       for (int i = 0; i < N; ++i) SG_CHECK(drt::graph_launch(&graph_, stream_));
     } else {
@@ -513,6 +508,7 @@ class Engine {
   void set_ragged_frames(const int* frames, int n) { set_frames(frames, n); }     // sgmse_set_frames
   int last_nfe() const { return nfe_; }
   int graph_captures() const { return graph_captures_; }     // how many times a step was captured + instantiated (tests, bench)
+  int graph_updates() const { return graph_updates_; }       // ... captured and applied to the existing executable in place
   int split_mode() const { return split_mode_; }
   size_t arena_bytes() const { return arena_cap_; }
 
@@ -789,7 +785,27 @@ class Engine {
   }
   void check_launch() { SG_CHECK(drt::last_error()); }
   void require_ready() { SG_REQUIRE(weights_ready_, "weights not loaded (call sgmse_load_weights first)"); }
-  void invalidate_graph() { if (graph_valid_) { drt::graph_destroy(&graph_); graph_valid_ = false; } }
+  // A captured step that no longer matches (new shape, new ragged composition, new weights) is not destroyed but kept as the
+  // target of an in-place update by the next capture (capture_step): same launch sequence, other arguments.
+  void invalidate_graph() { if (graph_valid_) { graph_valid_ = false; graph_stale_ = true; } }
+  void drop_graph() { if (graph_valid_ || graph_stale_) { drt::graph_destroy(&graph_); graph_valid_ = graph_stale_ = false; } }
+  template <class Body>
+  void capture_step(Body&& body) {
+    SG_CHECK(drt::stream_sync(stream_));
+    SG_CHECK(drt::graph_begin_capture(stream_));
+    body();
+    if (graph_stale_) {
+      const int r = drt::graph_end_capture_update(stream_, &graph_);
+      if (r > 0) { graph_stale_ = false; SG_CHECK(r); }
+      if (r == 0) ++graph_updates_; else ++graph_captures_;
+    } else {
+      SG_CHECK(drt::graph_end_capture(stream_, &graph_));
+      ++graph_captures_;
+    }
+    graph_stale_ = false;
+    graph_valid_ = true;
+  }
+  bool graph_stale_ = false; int graph_updates_ = 0;
 
   const float2* twiddle(int n_fft) {
     auto it = twiddles_.find(n_fft);
@@ -997,10 +1013,11 @@ class Engine {
     }
     if (nrows > temb_rows_) {
       invalidate_graph();
-      if (temb_act_) { dev_free_owned(temb_act_); dev_free_owned(bias_table_); dev_free_owned(step_table_); dev_free_owned(tsteps_); dev_free_owned(coef_table_); }
+      if (temb_act_) { dev_free_owned(temb_act_); dev_free_owned(bias_table_); dev_free_owned(step_table_); dev_free_owned(tsteps_); dev_free_owned(coef_table_); dev_free_owned(bias_cur_); }
       temb_rows_ = std::max(nrows, 64);
       temb_act_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * 4 * cfg_.nf * 4));
       bias_table_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * std::max(tot_temb_, 1) * 4));
+      bias_cur_ = static_cast<float*>(dev_alloc((size_t)std::max(tot_temb_, 1) * 4));
       step_table_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * SC_STRIDE * 4));
       tsteps_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * 4));
       coef_table_ = static_cast<float*>(dev_alloc((size_t)temb_rows_ * 16));
@@ -1243,7 +1260,7 @@ class Engine {
     ca.amax_out = o.amax;
     ca.src1 = a.p; ca.src2 = b ? b->p : nullptr; ca.C1 = a.C; ca.C2 = b ? b->C : 0;
     ca.bias = bias; ca.bias2 = bias2; ca.bias2_bstride = ctl.bias_bstride; ca.bias2_sstride = ctl.bias_sstride;
-    ca.step_ptr = bias2 ? ctl.step_ptr : nullptr;
+    ca.step_ptr = bias2 ? ctl.bias_step : nullptr;
     ca.in_scale = xf.scale; ca.in_shift = xf.shift; ca.in_act = xf.act;
     ca.res = res; ca.out_scale = out_scale; ca.out = o.p; ca.Cout = w.cout; ca.B = B_; ca.H = a.H; ca.W = a.W;
     if (ragged()) {
@@ -1409,7 +1426,15 @@ class Engine {
 
   // NCSNpp.forward (ncsnpp.py:256-419) / NCSNpp_48k.forward
   void run_forward(const float2* x, long long xbs, const float2* y, long long ybs, float2* out, int B, int F, int T,
-                   const FwdCtl& ctl) {
+                   const FwdCtl& ctl_in) {
+    FwdCtl ctl = ctl_in;
+    ctl.bias_step = ctl.step_ptr;
+    if (!dry_ && ctl.step_ptr && ctl.bias_table && ctl.bias_bstride == 0 && tot_temb_ > 0) {
+      // sampler loop: this step's bias row into a fixed buffer (bias_select_kernel), the convolutions read it without indirection
+      DRT_LAUNCH(bias_select_kernel, dim3((tot_temb_ + 255) / 256), dim3(256), stream_, ctl.bias_table, ctl.bias_sstride, ctl.step_ptr,
+                 bias_cur_, tot_temb_);
+      ctl.bias_table = bias_cur_; ctl.bias_sstride = 0; ctl.bias_step = nullptr;
+    }
     B_ = B;
     cur_F_ = F;
     amax_next_ = 0;
@@ -1668,6 +1693,7 @@ class Engine {
   float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr, *sy_ = nullptr; size_t samp_n_ = 0;
   int* step_ctr_ = nullptr;
   float *lang_partial_ = nullptr, *lang_scal_ = nullptr;
+  float* bias_cur_ = nullptr;
   float *temb_act_ = nullptr, *bias_table_ = nullptr, *step_table_ = nullptr, *tsteps_ = nullptr, *coef_table_ = nullptr; int temb_rows_ = 0;
   drt::graph_t graph_{}; bool graph_valid_ = false; GraphKey graph_key_{};
   int nfe_ = 0;

@@ -510,12 +510,26 @@ __global__ __launch_bounds__(256) void sampler_sb_kernel(SamplerArgs p) {
   const float* tb = p.table + (size_t)step * SC_STRIDE;
   const float wp = tb[SB_WPREV], we = tb[SB_WEST], wy = tb[SB_WY], wz = tb[SB_WZ];
   const float2 xv = p.x[i], ev = p.score[i], yv = p.y[i];
-  float2 r = make_float2(wp * xv.x + we * ev.x + wy * yv.x, wp * xv.y + we * ev.y + wy * yv.y);
+  // The reference's rounding sequence, product by product and sum by sum (sampling/__init__.py:200-206, 226-233: torch evaluates
+  // w_prev*xt, w_est*est, their sum, w_y*y (or w_z*z), the sum), WITHOUT fused multiply-adds: the ODE's first step is
+  // x = 5457.15 y + 0.446 est - 5456.54 y (k = 2.6, c = 0.4, N = 4; x_0 = y), a cancellation of 4 digits, so a differently
+  // rounded sum is off by ~3e-4 |y| there -- what put the 'ode' sampler at 7.3e-5 of the reference's output in round 2 while
+  // the CPU oracle, which shares torch's sequence, sat at 9.6e-6.
+  float2 r = make_float2(drt_add_rn(drt_add_rn(drt_mul_rn(wp, xv.x), drt_mul_rn(we, ev.x)), drt_mul_rn(wy, yv.x)),
+                         drt_add_rn(drt_add_rn(drt_mul_rn(wp, xv.y), drt_mul_rn(we, ev.y)), drt_mul_rn(wy, yv.y)));
   if (p.add_noise) {
     const float2 z = sampler_noise(p, i, p.draw_base + step * p.draw_per_step);
-    r.x += wz * z.x; r.y += wz * z.y;
+    r.x = drt_add_rn(r.x, drt_mul_rn(wz, z.x)); r.y = drt_add_rn(r.y, drt_mul_rn(wz, z.y));
   }
   p.x[i] = r;
+}
+
+// the current step's row of the time-embedding bias table -> a fixed buffer, once per network evaluation: the ~50 convolutions
+// that add it then read a known address instead of each chasing the device step counter first (a dependent memory round trip
+// in front of every one of them, which a launch of few workgroups -- batch 1 -- cannot hide)
+__global__ __launch_bounds__(256) void bias_select_kernel(const float* table, int sstride, const int* step_ptr, float* out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = table[(size_t)(*step_ptr) * sstride + i];
 }
 
 __global__ void step_set_kernel(int* step, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *step = v; }

@@ -187,6 +187,27 @@ struct ConvTile {
 // their loads overlap the first K-stage's loads instead of delaying the epilogue and the epilogue neither holds 16 bias
 // registers nor adds them (as = the power of two that takes the accumulator back to the unscaled convolution: the
 // division is exact).  Returns the value for accumulator register r of every pixel fragment of channel fragment `frag`.
+// conv_acc_raw: the loads (bias + time-embedding row, unscaled) -- issue them with the prologue's other independent loads;
+// conv_acc_init: the same followed by the division.
+template <class T>
+__device__ __forceinline__ void conv_acc_raw(const ConvArgs& p, int b, int co_blk, int frag, int kh, float (&init)[16]) {
+  const float* b2 = nullptr;
+  if (p.bias2) {
+    const int step = p.step_ptr ? *p.step_ptr : 0;
+    b2 = p.bias2 + (size_t)step * p.bias2_sstride + (size_t)b * p.bias2_bstride;
+  }
+  const int co_l = co_blk * T::CO_T + frag * 32 + 4 * kh;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) init[r] = 0.f;
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int co = co_l + (r & 3) + 8 * (r >> 2); init[r] = p.bias[co < p.Cout ? co : 0]; }
+  }
+  if (b2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int co = co_l + (r & 3) + 8 * (r >> 2); init[r] += b2[co < p.Cout ? co : 0]; }
+  }
+}
 template <class T>
 __device__ __forceinline__ void conv_acc_init(const ConvArgs& p, int b, int co_blk, int frag, int kh, float as_mul, float (&init)[16]) {
   const float as = (p.acc_scale ? *p.acc_scale : 1.0f) * as_mul;

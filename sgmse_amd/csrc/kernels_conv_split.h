@@ -259,22 +259,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   const int x0 = tx * 32, y0 = ty * ROWS;
   // fp16x2 input scale of THIS utterance: the power of two that puts the bound gn_finalize_kernel derived from the utterance's
   // own statistics (ConvArgs::xbound) in [2^13, 2^14); undone exactly on the accumulator side (inv_kx)
-  float kx = 1.f;
-  if constexpr (S::SCALED) { if (p.xbound) kx = h2_weight_scale(amax_read(p.xbound, b)); }
-  const float inv_kx = 1.f / kx;
-  {
-    const bool xform = p.in_scale != nullptr;
-    constexpr float nl2e = -1.4426950408889634f;
-    for (int c = tid; c < Cin; c += 256) {
-      const float sc = xform ? p.in_scale[b * Cin + c] : 1.f, sh = xform ? p.in_shift[b * Cin + c] : 0.f;
-      if constexpr (NCO == 4) {
-        f32x4 v;
-        v[0] = sc * kx; v[1] = sh * kx; v[2] = sc * nl2e; v[3] = sh * nl2e;
-        reinterpret_cast<f32x4*>(s_co)[c] = v;
-      } else {
-        s_co[2 * c] = sc * kx; s_co[2 * c + 1] = sh * kx;
-      }
-    }
+  // Prologue latency (what a launch of few workgroups -- batch 1 -- pays per convolution): every INDEPENDENT global load of the
+  // prologue is issued before the first result is waited for -- the range-bound word, this thread's producer coefficients
+  // (channels tid and tid + 256; Cin <= 512), the bias / time-embedding terms, the first stage's raw inputs, the first weight
+  // fragments -- so that they cost one memory round trip together instead of one each.
+  float xb_raw = 0.f;
+  if constexpr (S::SCALED) { if (p.xbound) xb_raw = p.xbound[b * kAmaxSpread + (tid & (kAmaxSpread - 1))]; }
+  float csc[2], csh[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = tid + 256 * k;
+    const bool ld = p.in_scale != nullptr && c < Cin;
+    csc[k] = ld ? p.in_scale[b * Cin + (c < Cin ? c : 0)] : 1.f;
+    csh[k] = ld ? p.in_shift[b * Cin + (c < Cin ? c : 0)] : 0.f;
   }
   const unsigned HW = (unsigned)H * (unsigned)W;
 
@@ -362,8 +359,55 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     for (int s = 0; s < NS; ++s) sbuf[it_loff[i] + s] = pk[s];
   };
 
-  // accumulators start from (bias + time-embedding row) / acc_scale (conv_acc_init): no bias work in the epilogue
   const int wc = THIN ? 0 : wave % WCW, wp = THIN ? wave : wave / WCW;     // this wave's channel / pixel position in the block
+  const int nst = Cin / C::KC;
+  // this workgroup's K-stages: all of them, or (split-K) one chunk
+  int st0 = 0, st1 = nst;
+  if constexpr (CHK) {
+    if (gridDim.z > 1) { st0 = (int)blockIdx.z * p.kchunk_stages; st1 = st0 + p.kchunk_stages < nst ? st0 + p.kchunk_stages : nst; }
+  }
+  // accumulators start from (bias + time-embedding row) / acc_scale: no bias work in the epilogue.  Raw terms now (loads),
+  // scaled once the input scale is known.
+  float acc_raw[(SC || CHK) ? 1 : FCW][16];
+  if constexpr (!(SC || CHK)) {
+#pragma unroll
+    for (int i = 0; i < FCW; ++i) conv_acc_raw<T>(p, b, co_blk, wc * FCW + i, kg, acc_raw[i]);
+  }
+  float sc_m1 = 0.f, sc_m2 = 0.f;
+  if constexpr (SC) {
+    sc_m1 = p.sc_amax1[b * kAmaxSpread + (tid & (kAmaxSpread - 1))];
+    if (p.sc_amax2) sc_m2 = p.sc_amax2[b * kAmaxSpread + (tid & (kAmaxSpread - 1))];
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::NIT; ++i) load_item(i, st0 * C::KC);      // first stage's raw inputs (into s_in0 below)
+  }
+  // fp16x2 input scale of THIS utterance: the power of two that puts the bound gn_finalize_kernel derived from the utterance's
+  // own statistics (ConvArgs::xbound) in [2^13, 2^14); undone exactly on the accumulator side (inv_kx)
+  float kx = 1.f;
+  if constexpr (S::SCALED) {
+    if (p.xbound) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) xb_raw = fmaxf(xb_raw, __shfl_xor(xb_raw, o));
+      kx = h2_weight_scale(xb_raw);
+    }
+  }
+  const float inv_kx = 1.f / kx;
+  {
+    constexpr float nl2e = -1.4426950408889634f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = tid + 256 * k;
+      if (c < Cin) {
+        if constexpr (NCO == 4) {
+          f32x4 v;
+          v[0] = csc[k] * kx; v[1] = csh[k] * kx; v[2] = csc[k] * nl2e; v[3] = csh[k] * nl2e;
+          reinterpret_cast<f32x4*>(s_co)[c] = v;
+        } else {
+          s_co[2 * c] = csc[k] * kx; s_co[2 * c + 1] = csh[k] * kx;
+        }
+      }
+    }
+  }
   f32x16 acc[FCW][FPW];
 #pragma unroll
   for (int i = 0; i < FCW; ++i) {
@@ -372,7 +416,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) init[r] = 0.f;
     } else {
-      conv_acc_init<T>(p, b, co_blk, wc * FCW + i, kg, inv_kx, init);
+      const float inv = 1.0f / ((p.acc_scale ? *p.acc_scale : 1.0f) * inv_kx);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) init[r] = acc_raw[i][r] * inv;
     }
 #pragma unroll
     for (int j = 0; j < FPW; ++j)
@@ -380,18 +426,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = init[r];
   }
 
-  const int nst = Cin / C::KC;
   // A fragments of this wave: [co_blk][stage][tap][split][wave][lane] (THIN: every wave uses fragment 0); uniform
   // fragment pointer + lane byte offset
   const u32x4* wblk = reinterpret_cast<const u32x4*>(p.w) + (size_t)co_blk * nst * 9 * NS * 4 * 64;
   const unsigned a_boff = (unsigned)((wc * FCW * 64 + lane) * 16);
+  // THIN: the fragment is the layer's Cout (4) real output channels zero-padded to 32, and all four waves need the same one.
+  // Loading the padding costs L2 bandwidth like real data -- 72 KB of fragments per workgroup and stage against 22 KB of staged
+  // input, 9.4 GB per full-resolution launch at batch 32 -- so only the lanes that hold a real channel load (exec-masked: no
+  // traffic for the others), the rest keep zeros.  (Less traffic, same time: see the thin loop below.)
+  const bool a_real = !THIN || l31 < p.Cout;
   auto load_a = [&](int st, int tap, u32x4 (&a)[FCW][NS]) {
     const u32x4* q = wblk + (size_t)(st * 9 + tap) * NS * 4 * 64;
 #pragma unroll
     for (int i = 0; i < FCW; ++i)
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
-        a[i][s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s * 4 * 64 + i * 64) + a_boff);
+      for (int s = 0; s < NS; ++s) {
+        if constexpr (THIN) {
+          a[i][s] = u32x4{0u, 0u, 0u, 0u};
+          if (a_real) a[i][s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s * 4 * 64 + i * 64) + a_boff);
+        } else {
+          a[i][s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s * 4 * 64 + i * 64) + a_boff);
+        }
+      }
   };
   // B fragment base of this lane inside a stage buffer (u32x4 units): pixel (row j + dy, col l31 + dx), k-group kg
   const int b_lane = l31 * PX_V + kg * NS + wp * FPW * C::TCOLS * PX_V;
@@ -433,8 +489,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   if constexpr (SC) {
     // ---- folded 1x1 shortcut: K-stages of 16 channels of the raw block input, centre tap only -------------------------------
     static_assert(S::SCALED && !THIN, "the folded shortcut exists for the fp16x2 full-block shapes");
-    float m = amax_read(p.sc_amax1, b);
-    if (p.sc_amax2) m = fmaxf(m, amax_read(p.sc_amax2, b));
+    float m = fmaxf(sc_m1, sc_m2);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     const float xs = h2_weight_scale(m);                 // max |x| 2^s in [2^13, 2^14) for this utterance
     const int nsts = (p.sc_C1 + p.sc_C2) / C::KC;
     // raw inputs two stages ahead in two register sets: a stage has only 24 MFMAs per wave to cover its loads
@@ -511,14 +568,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * rho + init[r];
     }
   }
-  // this workgroup's K-stages: all of them, or (split-K) one chunk
-  int st0 = 0, st1 = nst;
-  if constexpr (CHK) {
-    if (gridDim.z > 1) { st0 = (int)blockIdx.z * p.kchunk_stages; st1 = st0 + p.kchunk_stages < nst ? st0 + p.kchunk_stages : nst; }
-  }
-  // prologue: first stage -> s_in0
+  // prologue: first stage -> s_in0 (its raw loads were issued at the top; behind a folded shortcut they are issued here)
+  if constexpr (SC) {
 #pragma unroll
-  for (int i = 0; i < C::NIT; ++i) load_item(i, st0 * C::KC);
+    for (int i = 0; i < C::NIT; ++i) load_item(i, st0 * C::KC);
+  }
   __syncthreads();          // s_co and the zero padding visible
 #pragma unroll
   for (int i = 0; i < C::NIT; ++i) store_item(i, st0 * C::KC, s_in0);
@@ -534,13 +588,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   // (a ring holding a whole stage -- 9 sets, 8 taps ahead -- for the 4-row shape, whose taps have half the MFMAs to cover a
   // load, measured no gain at batch 1 and costs the third workgroup per CU: profiles/r02 gpu_r02_coarse.sh)
   if constexpr (THIN && !ABL) {
-    // ---- thin shape (C -> 4 pyramid convolutions): a tap is only 6 MFMAs per wave (~190 cycles), and vmcnt retires in order: with
-    // the fragment ring above, the wait for a fragment loaded two taps ahead also waits for the raw HBM loads of the next stage
-    // issued in front of it, ~400 cycles after their issue, every stage (2.0 ms per evaluation at batch 32 for 0.6 ms of HBM
-    // reads, profiles/r02_prof_dump_b32_final.txt).  Here the fragments of a WHOLE stage live in registers (9 x 8 VGPRs): the
-    // fragment of tap t is reloaded for the next stage right after tap t's MFMAs (a full stage of cover), and the raw inputs run
-    // TWO stages ahead in two register sets, an item reloaded as soon as the producer has consumed it (two stages of cover, ten
-    // taps before the next younger fragment is waited for).  Same K order, same arithmetic: bit-identical to the ring loop.
+    // ---- thin shape (C -> 4 pyramid convolutions): a tap is only 6 MFMAs per wave (~190 cycles), so the fragment ring above (two
+    // taps of cover, and vmcnt retires in order: a fragment wait also waits for the raw HBM loads issued in front of it) is
+    // replaced by: the fragments of a WHOLE stage in registers (9 x 8 VGPRs), the fragment of tap t reloaded for the next stage
+    // right after tap t's MFMAs (a full stage of cover), the raw inputs TWO stages ahead in two register sets, an item reloaded as
+    // soon as the producer has consumed it.  Same K order, same arithmetic: bit-identical to the ring loop.
+    // MEASURED (round 3, profiles/r03_prof_dump_b32.txt): neither this nor the exec-masked fragment loads (load_a) moved these
+    // layers -- 128 -> 4 @ 32 x 256 x 512 stays at 1.41 ms.  They are not bound by memory latency or L2 bandwidth but by issue
+    // slots: a workgroup stages the same 10 x 34 x 16 tile as a full 128-channel block (producer: ~66 wave-cycles per element,
+    // 24 elements per thread and stage ~ 1600 cycles) and has only its 54 MFMAs per wave and stage (~1730 cycles) to put beside
+    // it; 2 waves per SIMD x (1600 + 1730) = 6.7 k cycles per stage pair against 11 k measured.  What would help is less producer
+    // work per output (the halo is 1.33 x) or a 16-row MFMA for the 4 real channels -- another kernel, for 1.9 % of the evaluation.
     static_assert(FCW == 1, "thin shape");
     float rin2[C::NIT][8];
     u32x4 af[9][FCW][NS];

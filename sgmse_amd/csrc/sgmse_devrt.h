@@ -36,6 +36,10 @@ __device__ __forceinline__ uint32_t drt_f32x2_to_f16x2(float x0, float x1) {
   const f2_t v = {x0, x1};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2_t));
 }
+// IEEE single multiply / add that the compiler must not contract into a fused multiply-add (where a reference's rounding
+// sequence has to be reproduced operation by operation)
+__device__ __forceinline__ float drt_mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float drt_add_rn(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float drt_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 // Raw buffer view of a global fp32 tensor slice: address = base + voff (per-lane VGPR, bytes) + soff (uniform SGPR, bytes).
 // One buffer_load/store_dword per access with NO address arithmetic on the vector ALU; offsets must stay below 2^31.
@@ -127,6 +131,30 @@ inline int graph_end_capture(stream_t st, graph_t* g) {
   hipError_t e = hipStreamEndCapture(st, &g->g);
   if (e != hipSuccess) return int(e);
   return int(hipGraphInstantiate(&g->x, g->g, nullptr, nullptr, 0));
+}
+// end a capture whose graph has the topology of an already instantiated one (the same launch sequence with other arguments /
+// grids: a new ragged batch composition, new buffers): update the executable in place instead of instantiating a new one
+// (~1400 kernel nodes: instantiation is the expensive part of a re-capture).  Non-zero: the update was refused (topology
+// differs) -- the caller instantiates afresh.
+inline int graph_end_capture_update(stream_t st, graph_t* g) {
+  hipGraph_t ng = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &ng);
+  if (e != hipSuccess) return int(e);
+  hipGraphNode_t bad = nullptr;
+  hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
+  e = hipGraphExecUpdate(g->x, ng, &bad, &res);
+  if (e == hipSuccess && res == hipGraphExecUpdateSuccess) {
+    if (g->g) (void)hipGraphDestroy(g->g);
+    g->g = ng;
+    return 0;
+  }
+  (void)hipGetLastError();
+  // refused: fall back to a fresh executable of the new graph
+  if (g->x) (void)hipGraphExecDestroy(g->x);
+  if (g->g) (void)hipGraphDestroy(g->g);
+  g->x = nullptr; g->g = ng;
+  e = hipGraphInstantiate(&g->x, g->g, nullptr, nullptr, 0);
+  return e == hipSuccess ? -1 : int(e);      // -1: worked, but as a new instantiation
 }
 inline int graph_launch(graph_t* g, stream_t st) { return int(hipGraphLaunch(g->x, st)); }
 inline int graph_destroy(graph_t* g) {

@@ -73,6 +73,8 @@ static inline unsigned drt_hw_id() { return 0; }
 static inline unsigned drt_xcc_id() { return 0; }
 static inline uint32_t drt_f32x2_to_f16x2(float x0, float x1) { return emu::f32_to_f16(x0) | (emu::f32_to_f16(x1) << 16); }
 static inline float drt_exp2(float x) { return exp2f(x); }
+static inline float drt_mul_rn(float a, float b) { volatile float r = a * b; return r; }     // (volatile: no contraction whatever the flags)
+static inline float drt_add_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline void drt_atomic_max_nonneg(float* p, float v) {
   uint32_t* ip = reinterpret_cast<uint32_t*>(p);
   uint32_t nv; memcpy(&nv, &v, 4);
@@ -142,6 +144,7 @@ inline float event_elapsed_ms(const event_t& a, const event_t& b) { return float
 inline bool graphs_supported() { return false; }
 inline int graph_begin_capture(stream_t) { return 1; }
 inline int graph_end_capture(stream_t, graph_t*) { return 1; }
+inline int graph_end_capture_update(stream_t, graph_t*) { return 1; }
 inline int graph_launch(graph_t*, stream_t) { return 1; }
 inline int graph_destroy(graph_t*) { return 0; }
 inline int device_count() { return 1; }

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--N", type=int, default=30)
     ap.add_argument("--modes", default="ragged,bucketed,uniform")
     ap.add_argument("--test-emulator", default=None)
+    ap.add_argument("--profile", action="store_true", help="also one instrumented evaluation of the ragged and the uniform batch (per kernel class)")
     a = ap.parse_args()
     from sgmse_amd import _lib
     from sgmse_amd.model import ScoreModel
@@ -76,6 +77,14 @@ def main():
         sync()
         out[mode + "_s"] = round(time.perf_counter() - t0, 4)
         print(mode, out[mode + "_s"], "s", flush=True)
+    if a.profile and not emu:
+        # one instrumented evaluation each (eager, HIP events per kernel class): where the mixing costs
+        ctx = model.dnn.engine(dev)
+        tt = torch.full((a.batch,), 0.5, device=dev)
+        xr = [torch.cat([Y[0], Y[0]]) for Y in Ys]                       # [2,F,T_b]
+        pr, _ = ctx.profile_forward(xr, tt)
+        pu, _ = ctx.profile_forward(torch.cat([Yu, Yu], dim=1), tt)
+        out["classes_ms_ragged_vs_uniform"] = {k: [round(pr[k]["ms"], 3), round(pu[k]["ms"], 3)] for k in pr}
     if "uniform_s" in out and "ragged_s" in out:
         out["ragged_vs_uniform_per_frame"] = round((out["ragged_s"] / sum(frames)) / (out["uniform_s"] / (a.batch * int(Yu.shape[-1]))), 4)
     print(json.dumps(out))
