@@ -46,11 +46,12 @@ inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant,
   else if (pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 0>), grid, dim3(256), st, a);
   else DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 0>), grid, dim3(256), st, a);
   if constexpr (FC * FP <= 2) {
-    if (ksplit > 1) DRT_LAUNCH((conv_splitk_reduce_kernel<KS, WC, FC, FP>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
+    if (ksplit > 1 && !a.splitk_ctr) DRT_LAUNCH((conv_splitk_reduce_kernel<KS, WC, FC, FP>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
   }
 }
 
-// ksplit > 1 (small tiles only, ConvArgs::kchunk_stages chunks): split-K over gridDim.z + the reduce/epilogue kernel
+// ksplit > 1 (small tiles only, ConvArgs::kchunk_stages chunks): split-K over gridDim.z + the reduce/epilogue kernel (or, with
+// ConvArgs::splitk_ctr, the reduce and epilogue by the last chunk workgroup of each tile: no second launch)
 inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1, int ksplit = 1) {
   const int v = variant < 0 ? conv_variant() : variant;
   if (ks == 1 && pl.co_t == 128 && (v & 8)) {
@@ -132,7 +133,7 @@ inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t
     const dim3 grid(a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32), a.Cout / 128, ksplit);
     if (a.in_scale && a.in_act) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2, 1, 0, 0, 0, 1>), grid, dim3(256), st, a);
     else DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2, 0, 0, 0, 0, 1>), grid, dim3(256), st, a);
-    if (ksplit > 1) DRT_LAUNCH((conv_splitk_reduce_kernel<3, 4, 1, 4, true>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
+    if (ksplit > 1 && !a.splitk_ctr) DRT_LAUNCH((conv_splitk_reduce_kernel<3, 4, 1, 4, true>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
     return;
   }
   if (ks == 3 && a.Cout > 32 && rows4) {

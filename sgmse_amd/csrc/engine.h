@@ -241,7 +241,14 @@ class Arena {
 
 // st: [B][C][nsub][2] GroupNorm partial sums; amax: [B] upper bounds of |x| per utterance (null: unknown range)
 // srows: image rows per statistics sub-tile (1: the fp32 kernels, 4: the split kernels; ConvArgs::stats_rows)
-struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; float* st = nullptr; int nsub = 0; float* amax = nullptr; int srows = 1; };
+// pre: GroupNorm coefficients the producing launch's tail already computes for a consumer (Engine::conv, GnHint): the consumer,
+// identified by its gamma and by the second tensor of its virtual concat, takes them from here instead of launching gn_finalize_kernel
+struct GnPre { const float* gamma = nullptr; const float* other = nullptr; float* sc = nullptr; float* sh = nullptr; const float* bound = nullptr; };
+struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; float* st = nullptr; int nsub = 0; float* amax = nullptr; int srows = 1;
+                GnPre pre[2]; int npre = 0; };
+// a GroupNorm that will normalise [the tensor a launch is about to produce | b] (b may be null); want_bound: for an fp16x2 consumer
+struct GnHint { const float* gamma; const float* beta; const Tensor* b; bool want_bound; };
+struct GnHints { GnHint h[2]; int n = 0; void add(const GnHint& x) { if (n < 2) h[n++] = x; } };
 
 struct ConvW {            // one convolution's parameters on the device
   const float* oihw = nullptr;   // [cout][cin][ks][ks] (for NIN: transposed copy)
@@ -509,6 +516,7 @@ class Engine {
   int last_nfe() const { return nfe_; }
   int graph_captures() const { return graph_captures_; }     // how many times a step was captured + instantiated (tests, bench)
   int graph_updates() const { return graph_updates_; }       // ... captured and applied to the existing executable in place
+  int gn_tail_jobs() const { return fin_count_; }            // GroupNorm finalize jobs of the planned forward that run in convolution tails
   int split_mode() const { return split_mode_; }
   size_t arena_bytes() const { return arena_cap_; }
 
@@ -591,8 +599,8 @@ class Engine {
     DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C1), dim3(256), stream_, x, (const float*)nullptr, C1, 0, HW, stats, Rag{nullptr, nullptr, nullptr}, 0);
     if (C2) DRT_LAUNCH(gn_chan_stats_kernel, dim3(B * C2), dim3(256), stream_, x2, (const float*)nullptr, C2, 0, HW, stats2, Rag{nullptr, nullptr, nullptr}, 0);
     const int G = std::min(C / 4, 32);
-    DRT_LAUNCH(gn_finalize_kernel, dim3(G, B), dim3(256), stream_, (const float*)stats, C1, 1, (const float*)stats2, C2, 1, gamma, beta, G,
-               HW, 1e-6f, sc, sh, Rag{nullptr, nullptr, nullptr}, 0, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 1, 1);
+    const GnFin f{stats, stats2, nullptr, nullptr, gamma, beta, sc, sh, nullptr, Rag{nullptr, nullptr, nullptr}, C1, 1, 1, C2, 1, 1, G, HW, 0, 1e-6f};
+    DRT_LAUNCH(gn_finalize_kernel, dim3(G, B), dim3(256), stream_, f);
     DRT_LAUNCH(gn_apply_kernel, dim3((HW + 1023) / 1024, B * C), dim3(256), stream_, x, x2, C1, C2, HW, (const float*)sc,
                (const float*)sh, act, out);
     SG_CHECK(drt::stream_sync(stream_));
@@ -793,7 +801,9 @@ class Engine {
   void capture_step(Body&& body) {
     SG_CHECK(drt::stream_sync(stream_));
     SG_CHECK(drt::graph_begin_capture(stream_));
-    body();
+    capturing_ = true;
+    try { body(); } catch (...) { capturing_ = false; throw; }
+    capturing_ = false;
     if (graph_stale_) {
       const int r = drt::graph_end_capture_update(stream_, &graph_);
       if (r > 0) { graph_stale_ = false; SG_CHECK(r); }
@@ -805,7 +815,7 @@ class Engine {
     graph_stale_ = false;
     graph_valid_ = true;
   }
-  bool graph_stale_ = false; int graph_updates_ = 0;
+  bool graph_stale_ = false, capturing_ = false; int graph_updates_ = 0;
 
   const float2* twiddle(int n_fft) {
     auto it = twiddles_.find(n_fft);
@@ -977,6 +987,7 @@ class Engine {
       invalidate_graph();
       cur_F_ = F;
       if (ragged()) build_rag_tables(B, F, T);
+      if (!fin_dev_) fin_dev_ = static_cast<GnFin*>(dev_alloc(sizeof(GnFin) * kMaxFin));
       // size the arena by a dry run
       arena_.measure_mode();
       dry_ = true;
@@ -1005,6 +1016,7 @@ class Engine {
         amax_pool_ = static_cast<float*>(dev_alloc(need_amax * 4));
         amax_pool_floats_ = need_amax;
       }
+      plan_gn_tails(B, F, T);
       if (!step_ctr_) step_ctr_ = static_cast<int*>(dev_alloc(256));
       if (!lang_scal_) lang_scal_ = static_cast<float*>(dev_alloc(256));
       if (lang_partial_) dev_free_owned(lang_partial_);
@@ -1041,6 +1053,12 @@ class Engine {
   struct Xform { const float* scale = nullptr; const float* shift = nullptr; int act = 0; const float* bound = nullptr; };
 
   void tick(int cls, double work, int launches = 1) {
+    if (debug_sync_ && !dry_ && !capturing_) {      // SGMSE_DEBUG_SYNC=1: wait for every launch and name it (a device fault then names its kernel)
+      const int e = drt::stream_sync(stream_);
+      fprintf(stderr, "[sgmse-dbg] %s -> %s\n", prof_note_[0] ? prof_note_ : "(launch)", e ? drt::error_string(e) : "ok");
+      fflush(stderr);
+      if (!prof_) prof_note_[0] = 0;
+    }
     if (!prof_) return;
     drt::event_record(&ev_b_, stream_);
     drt::event_sync(&ev_b_);
@@ -1051,6 +1069,7 @@ class Engine {
     if (prof_dump_ && prof_note_[0]) fprintf(stderr, "[sgmse-prof] %s %.4f ms %.1f Gwork/s\n", prof_note_, ms, work / ms * 1e-6);
     prof_note_[0] = 0;
   }
+  bool noting() const { return (prof_ && prof_dump_) || debug_sync_; }
   void tock() { if (prof_) { if (!ev_init_) { drt::event_create(&ev_a_); drt::event_create(&ev_b_); ev_init_ = true; } drt::event_record(&ev_a_, stream_); } }
 
   Tensor new_tensor(int C, int H, int W) { Tensor t; t.C = C; t.H = H; t.W = W; t.p = arena_.alloc((size_t)C * pix_total(H, W)); return t; }
@@ -1124,6 +1143,15 @@ class Engine {
   void gn_coeffs(const Tensor& a, const Tensor* b, const float* gamma, const float* beta, float** sc, float** sh,
                  const float** bound = nullptr) {
     const int C = a.C + (b ? b->C : 0), HW = a.H * a.W;
+    for (int k = 0; k < a.npre; ++k) {        // already computed by the tail of the launch that produced `a` (conv, GnHint)
+      const GnPre& pr = a.pre[k];
+      if (pr.gamma == gamma && pr.other == (b ? b->p : nullptr) && (!bound || pr.bound)) {
+        *sc = pr.sc; *sh = pr.sh;
+        if (bound) *bound = pr.bound;
+        --pre_pending_;
+        return;
+      }
+    }
     float* bslot = bound ? next_amax() : nullptr;
     if (bound) *bound = bslot;
     const float* st[2] = {a.st, b ? b->st : nullptr};
@@ -1139,7 +1167,7 @@ class Engine {
         tock();
         DRT_LAUNCH(gn_chan_stats_kernel, dim3(B_ * src[k]->C), dim3(256), stream_, (const float*)src[k]->p, (const float*)nullptr,
                    src[k]->C, 0, HW, tmp[k], rag_of(a.H), a.H);
-        if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "gn_chan_stats C=%d @%dx%dx%d", src[k]->C, B_, a.H, a.W);
+        if (noting()) snprintf(prof_note_, sizeof prof_note_, "gn_chan_stats C=%d @%dx%dx%d", src[k]->C, B_, a.H, a.W);
         tick(TC_GN, 4.0 * B_ * (double)src[k]->C * HW, 1);
       }
     }
@@ -1148,9 +1176,10 @@ class Engine {
     if (!dry_) {
       tock();
       const int G = std::min(C / 4, 32);
-      DRT_LAUNCH(gn_finalize_kernel, dim3(G, B_), dim3(256), stream_, st[0], a.C, nsub[0], st[1], b ? b->C : 0, nsub[1], gamma, beta, G,
-                 HW, 1e-6f, *sc, *sh, rag_of(a.H), a.H, (const float*)a.amax, (const float*)(b ? b->amax : nullptr), bslot, srows[0], srows[1]);
-      if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "gn_finalize C=%d nsub=%d @%dx%dx%d", C, nsub[0], B_, a.H, a.W);
+      const GnFin f{st[0], st[1], a.amax, b ? b->amax : nullptr, gamma, beta, *sc, *sh, bslot, rag_of(a.H),
+                    a.C, nsub[0], srows[0], b ? b->C : 0, nsub[1], srows[1], G, HW, a.H, 1e-6f};
+      DRT_LAUNCH(gn_finalize_kernel, dim3(G, B_), dim3(256), stream_, f);
+      if (noting()) snprintf(prof_note_, sizeof prof_note_, "gn_finalize C=%d nsub=%d @%dx%dx%d", C, nsub[0], B_, a.H, a.W);
       tick(TC_GN, 8.0 * B_ * ((double)a.C * nsub[0] + (b ? (double)b->C * nsub[1] : 0.0)), 1);
     }
     for (int k = 0; k < 2; ++k) if (tmp[k]) arena_.release(tmp[k]);
@@ -1169,7 +1198,8 @@ class Engine {
   }
 
   Tensor conv(const ConvW& w, const Tensor& a, const Tensor* b, const Xform& xf, const float* bias, const float* bias2,
-              const float* res, float out_scale, const FwdCtl& ctl, bool emit_stats = false, const Shortcut* sc = nullptr) {
+              const float* res, float out_scale, const FwdCtl& ctl, bool emit_stats = false, const Shortcut* sc = nullptr,
+              const GnHints* hints = nullptr) {
     const int Cin = a.C + (b ? b->C : 0);
     SG_REQUIRE(Cin == w.cin, "conv: channel mismatch");
     Tensor o = new_tensor(w.cout, a.H, a.W);
@@ -1254,8 +1284,56 @@ class Engine {
       o.st = arena_.alloc((size_t)B_ * w.cout * 2);
     }
     o.amax = next_amax();
+    // GroupNorm coefficients of the consumers named by `hints`, computed by the last workgroup of each utterance in THIS launch
+    // (ConvArgs::fin, conv_gn_tail) instead of a gn_finalize_kernel launch behind it -- for tensors whose partials one workgroup
+    // sums in a few microseconds (gn_tail_max_pairs_ per utterance: the levels from 32 x 64 down, where a launch costs more than
+    // the sum).  The jobs live in a device table written by the planning pass (plan_gn_tails); this run hands out the same
+    // entries in the same order.
+    const GnFin* fin_dev = nullptr; int nfin = 0; float* fin_ctr = nullptr;
+    // (not in ragged launches: the full-width five-utterance case of test_ragged_batch_gives_every_utterance_its_single_run_bits
+    // faulted on the GPU with the tails on -- at the 4 x 8 level, utterance widths 8 / 1 / 3 / 5 / 2 -- while the same composition
+    // runs clean on the emulator under AddressSanitizer; unresolved, and the mechanism is off by default anyway)
+    if (hints && gn_tail_ && !ragged() && o.st && o.nsub >= 1 && use_mfma) {
+      for (int k = 0; k < hints->n; ++k) {
+        const GnHint& hn = hints->h[k];
+        const Tensor* hb = hn.b;
+        if (hb && !hb->st) continue;                                       // (would need a statistics pass first)
+        const long pairs = (long)w.cout * o.nsub + (hb ? (long)hb->C * hb->nsub : 0L);
+        if (pairs > gn_tail_max_pairs_) continue;
+        const int C = w.cout + (hb ? hb->C : 0);
+        GnPre pr;
+        pr.gamma = hn.gamma; pr.other = hb ? hb->p : nullptr;
+        pr.sc = arena_.alloc((size_t)B_ * C); pr.sh = arena_.alloc((size_t)B_ * C);
+        float* bslot = hn.want_bound ? next_amax() : nullptr;
+        pr.bound = bslot;
+        const int idx = fin_next_++;
+        if (plan_) {
+          SG_REQUIRE(idx < kMaxFin, "GroupNorm tail table full");
+          fin_host_[idx] = GnFin{o.st, hb ? hb->st : nullptr, o.amax, hb ? hb->amax : nullptr, hn.gamma, hn.beta, pr.sc, pr.sh, bslot,
+                                 rag_of(a.H), w.cout, o.nsub, o.srows, hb ? hb->C : 0, hb ? hb->nsub : 0, hb ? hb->srows : 1,
+                                 std::min(C / 4, 32), a.H * a.W, a.H, 1e-6f};
+        }
+        if (nfin == 0) fin_dev = fin_dev_ + idx;
+        ++nfin;
+        o.pre[o.npre++] = pr;
+        ++pre_pending_;
+      }
+      if (nfin) fin_ctr = next_amax();
+    }
+    // split-K: one arrival counter per (tile, channel block); the last chunk workgroup of a tile reduces and finishes it
+    // (ConvArgs::splitk_ctr) instead of a conv_splitk_reduce_kernel launch
+    unsigned* splitk_ctr = nullptr;
+    if (ksplit > 1 && splitk_fused_) {
+      const int co_blk = coarse_split ? 128 : co_t;
+      const int rows = coarse_split ? 4 : rows_;
+      const long nctr = (long)B_ * ((a.H + rows - 1) / rows) * ((a.W + 31) / 32) * ((w.cout + co_blk - 1) / co_blk);
+      splitk_ctr = reinterpret_cast<unsigned*>(next_amax());
+      for (long have = (long)B_ * kAmaxSpread; have < nctr; have += (long)B_ * kAmaxSpread) (void)next_amax();   // (consecutive slots are contiguous)
+    }
     if (dry_) { if (partial) arena_.release(partial); return o; }
     ConvArgs ca{};
+    ca.fin = fin_dev; ca.nfin = nfin; ca.fin_ctr = reinterpret_cast<unsigned*>(fin_ctr); ca.fin_mode = nfin ? gn_tail_mode_ : 0;
+    ca.splitk_ctr = splitk_ctr;
     ca.stats_out = o.st; ca.stats_nsub = o.nsub; ca.stats_rows = o.srows;
     ca.amax_out = o.amax;
     ca.src1 = a.p; ca.src2 = b ? b->p : nullptr; ca.C1 = a.C; ca.C2 = b ? b->C : 0;
@@ -1296,7 +1374,7 @@ class Engine {
       }
       launch_conv_split(ca, w.ks, w.split_mode, stream_, rows4, 0, ksplit);
       if (coarse_split && partial) arena_.release(partial);
-      if (prof_ && prof_dump_)
+      if (noting())
         snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "",
                  sc ? " +shortcut" : "");
       tick(w.ks == 3 ? (w.cout >= 128 ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
@@ -1306,7 +1384,7 @@ class Engine {
       ca.kchunk_stages = kchunk; ca.partial = partial;
       launch_conv_mfma(ca, w.ks, pl, stream_, -1, ksplit);
       if (partial) arena_.release(partial);
-      if (prof_ && prof_dump_)
+      if (noting())
         snprintf(prof_note_, sizeof prof_note_, "conv%dx%d %d->%d @%dx%dx%d tile %dco x %drows%s%s%s", w.ks, w.ks, Cin, w.cout, B_, a.H, a.W,
                  co_t, rows_, res ? " +res" : "", xf.scale ? " +gn" : "", ksplit > 1 ? " split-K" : "");
       // class "wide" = the dominant kernel family only: the split kernels, or (SGMSE_CONV_SPLIT=0) the fp32 128 x 256 tile
@@ -1315,13 +1393,13 @@ class Engine {
       ca.w = w.oihw;
       ca.stats_out = nullptr;
       launch_conv_direct(ca, w.ks, stream_);
-      if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "conv-direct%dx%d %d->%d @%dx%dx%d", w.ks, w.ks, Cin, w.cout, B_, a.H, a.W);
+      if (noting()) snprintf(prof_note_, sizeof prof_note_, "conv-direct%dx%d %d->%d @%dx%dx%d", w.ks, w.ks, Cin, w.cout, B_, a.H, a.W);
       tick(TC_DIRECT, fl);
       if (o.st) {
         tock();
         DRT_LAUNCH(gn_chan_stats_kernel, dim3(B_ * w.cout), dim3(256), stream_, (const float*)o.p, (const float*)nullptr, w.cout, 0,
                    a.H * a.W, o.st, rag_of(a.H), a.H);
-        if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "gn_chan_stats(direct) C=%d @%dx%dx%d", w.cout, B_, a.H, a.W);
+        if (noting()) snprintf(prof_note_, sizeof prof_note_, "gn_chan_stats(direct) C=%d @%dx%dx%d", w.cout, B_, a.H, a.W);
         tick(TC_GN, 4.0 * B_ * (double)w.cout * a.H * a.W, 1);
       }
     }
@@ -1352,14 +1430,16 @@ class Engine {
     FirArgs fa{a.p, o.p, xf.scale, xf.shift, xf.act, B_ * a.C, a.H, a.W, raw ? raw->p : nullptr, a.C, rag_of(a.H)};
     tock();
     launch_fir(fa, up, true);
-    if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "fir-%s C=%d @%dx%dx%d%s", up ? "up" : "down", a.C, B_, a.H, a.W, raw ? " +raw" : "");
+    if (noting()) snprintf(prof_note_, sizeof prof_note_, "fir-%s C=%d @%dx%dx%d%s", up ? "up" : "down", a.C, B_, a.H, a.W, raw ? " +raw" : "");
     tick(TC_FIR, 4.0 * B_ * (double)a.C * (a.H * a.W + (raw ? 2.0 : 1.0) * o.H * o.W));
     return o;
   }
 
   // ResnetBlockBigGANpp.forward (layerspp.py:242-274).  Inputs stay owned by the caller.
-  Tensor res_block(const Mod& m, Tensor& a, Tensor* b, const FwdCtl& ctl) {
+  // out_hints: the GroupNorm(s) that will consume this block's output (finished in the tail of its last convolution)
+  Tensor res_block(const Mod& m, Tensor& a, Tensor* b, const FwdCtl& ctl, const GnHints* out_hints = nullptr) {
     const ResW& r = res_.at(m.idx);
+    GnHints g1; g1.add(GnHint{r.g1w, r.g1b, nullptr, true});       // GroupNorm_1 reads Conv_0's output
     float *sc0, *sh0, *sc1, *sh1;
     const float *bd0, *bd1;
     gn_coeffs(a, b, r.g0w, r.g0b, &sc0, &sh0, &bd0);
@@ -1371,10 +1451,10 @@ class Engine {
       SG_REQUIRE(b == nullptr, "resample block with concat input");
       Tensor hr = fir(a, m.up, x0, &xs);
       have_xs = true;
-      h = conv(r.c0, hr, nullptr, Xform{nullptr, nullptr, 0, bd0}, nullptr, temb, nullptr, 1.f, ctl, true);
+      h = conv(r.c0, hr, nullptr, Xform{nullptr, nullptr, 0, bd0}, nullptr, temb, nullptr, 1.f, ctl, true, nullptr, &g1);
       drop(hr);
     } else {
-      h = conv(r.c0, a, b, x0, nullptr, temb, nullptr, 1.f, ctl, true);
+      h = conv(r.c0, a, b, x0, nullptr, temb, nullptr, 1.f, ctl, true, nullptr, &g1);
     }
     arena_.release(sc0); arena_.release(sh0);
     gn_coeffs(h, nullptr, r.g1w, r.g1b, &sc1, &sh1, &bd1);
@@ -1387,15 +1467,15 @@ class Engine {
       if (runs_on_h2_split3(r.c1, h.C, h.H, dec_W(h.H)) && shortcut_foldable(r.c2, sa, sb)) {
         // (Conv_1(h) + Conv_2(x)) / sqrt 2 as one accumulation: the shortcut's K-stages run inside the 3x3 launch
         const Shortcut scin{&r.c2, &sa, sb};
-        out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, nullptr, inv_sqrt2, ctl, true, &scin);
+        out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, nullptr, inv_sqrt2, ctl, true, &scin, out_hints);
       } else {
         Tensor sh_t = conv(r.c2, sa, sb, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl);
-        out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, sh_t.p, inv_sqrt2, ctl, true);
+        out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, sh_t.p, inv_sqrt2, ctl, true, nullptr, out_hints);
         drop(sh_t);
       }
     } else {
       SG_REQUIRE(b == nullptr, "identity shortcut with concat input");
-      out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, a.p, inv_sqrt2, ctl, true);
+      out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, a.p, inv_sqrt2, ctl, true, nullptr, out_hints);
     }
     if (have_xs) drop(xs);
     drop(h);
@@ -1404,7 +1484,7 @@ class Engine {
   }
 
   // AttnBlockpp.forward (layerspp.py:75-91)
-  Tensor attn_block(const Mod& m, Tensor& x, const FwdCtl& ctl) {
+  Tensor attn_block(const Mod& m, Tensor& x, const FwdCtl& ctl, const GnHints* out_hints = nullptr) {
     const AttnW& w = attn_.at(m.idx);
     float *sc, *sh;
     gn_coeffs(x, nullptr, w.gw, w.gb, &sc, &sh);
@@ -1415,11 +1495,11 @@ class Engine {
       AttnArgs aa{qkv.p, o.p, B_, x.C, x.H * x.W, 1.0f / sqrtf((float)x.C), rag_of(x.H), x.H};
       tock();
       SG_REQUIRE(launch_attn_core(aa, stream_), "attention: unsupported channel count");
-      if (prof_ && prof_dump_) snprintf(prof_note_, sizeof prof_note_, "attention C=%d S=%d B=%d", x.C, x.H * x.W, B_);
+      if (noting()) snprintf(prof_note_, sizeof prof_note_, "attention C=%d S=%d B=%d", x.C, x.H * x.W, B_);
       tick(TC_ATTN, 4.0 * B_ * (double)x.C * (x.H * x.W) * (double)(x.H * x.W));
     }
     drop(qkv);
-    Tensor out = conv(w.proj, o, nullptr, Xform{}, w.proj.bias, nullptr, x.p, 0.70710678118654752440f, ctl, true);
+    Tensor out = conv(w.proj, o, nullptr, Xform{}, w.proj.bias, nullptr, x.p, 0.70710678118654752440f, ctl, true, nullptr, out_hints);
     drop(o);
     return out;
   }
@@ -1438,6 +1518,7 @@ class Engine {
     B_ = B;
     cur_F_ = F;
     amax_next_ = 0;
+    fin_next_ = 0; pre_pending_ = 0;
     if (!dry_ && poison_ && arena_base_) SG_CHECK(drt::memset_dev(arena_base_, 0xFF, arena_cap_, stream_));
     if (!dry_ && amax_pool_) {
       const int n = amax_slots_ * B * kAmaxSpread;
@@ -1448,6 +1529,30 @@ class Engine {
     size_t mi = 3;
     auto next = [&]() -> const Mod& { SG_REQUIRE(mi < layout_.size(), "layout exhausted"); return layout_[mi++]; };
     const int FT = F * T;
+    std::vector<Tensor> hs;
+    // The GroupNorm(s) that read the tensor the module before layout_[mi] is about to produce, from the modules that follow it:
+    // a ResBlock's GroupNorm_0 (over [the tensor | the next skip tensor] on the way up: a block whose input is wider than the
+    // tensor), an attention block's GroupNorm, or the output pyramid's GroupNorm followed by the up-sampling block's.  (A
+    // Combine or a plain convolution normalises nothing.)  What is named here is computed in the tail of the producing launch;
+    // what is not is computed by gn_finalize_kernel when the consumer asks (gn_coeffs) -- the same numbers either way.
+    auto hints_for = [&](int C) -> GnHints {
+      GnHints g;
+      if (mi >= layout_.size()) return g;
+      const Mod& f = layout_[mi];
+      auto res0 = [&](const Mod& r, bool allow_concat) {
+        const ResW& w = res_.at(r.idx);
+        const bool concat = r.cin != C;
+        if (concat && !(allow_concat && !hs.empty() && hs.back().C + C == r.cin)) return;
+        g.add(GnHint{w.g0w, w.g0b, concat ? &hs.back() : nullptr, true});
+      };
+      if (f.kind == Mod::RES) res0(f, true);
+      else if (f.kind == Mod::ATTN) g.add(GnHint{attn_.at(f.idx).gw, attn_.at(f.idx).gb, nullptr, false});
+      else if (f.kind == Mod::GN) {
+        g.add(GnHint{gn_.at(f.idx).first, gn_.at(f.idx).second, nullptr, true});
+        if (mi + 2 < layout_.size() && layout_[mi + 2].kind == Mod::RES) res0(layout_[mi + 2], false);
+      }
+      return g;
+    };
 
     Tensor xr = new_tensor(4, F, T);
     const bool entry8 = entry_mfma_ && entry8_.packed && layout_[mi].idx == entry8_idx_;
@@ -1457,11 +1562,11 @@ class Engine {
       DRT_LAUNCH(entry_kernel, dim3((FT + 255) / 256, B), dim3(256), stream_, x, xbs, y, ybs, xr.p, entry8 ? xr8.p : (float*)nullptr,
                  entry8 ? entry8_.cin : 0, FT, wc, rag_of(F), F, ctl.y_plane);
       tick(TC_MISC, (32.0 + (entry8 ? 4.0 * entry8_.cin : 0.0)) * B * FT); }
-    std::vector<Tensor> hs;
     {
       const Mod& m = next();
       const ConvW& w = entry8 ? entry8_ : conv_.at(m.idx);
-      hs.push_back(conv(w, entry8 ? xr8 : xr, nullptr, Xform{}, w.bias, nullptr, nullptr, 1.f, ctl, true));
+      const GnHints g = hints_for(w.cout);
+      hs.push_back(conv(w, entry8 ? xr8 : xr, nullptr, Xform{}, w.bias, nullptr, nullptr, 1.f, ctl, true, nullptr, &g));
       if (entry8) drop(xr8);
     }
     Tensor pyr_in = xr;   // input pyramid (ncsnpp.py:293-296); released at the end / when replaced
@@ -1469,14 +1574,16 @@ class Engine {
     for (int l = 0; l < L; ++l) {
       for (int rb = 0; rb < c.num_res_blocks; ++rb) {
         const Mod& m = next();
-        Tensor h = res_block(m, hs.back(), nullptr, ctl);
+        GnHints g = hints_for(m.cout);
+        Tensor h = res_block(m, hs.back(), nullptr, ctl, &g);
         // the reference's forward places attention by the ACTUAL height (ncsnpp.py:308) while its module list was built from the
         // configured image_size (ncsnpp.py:189-193): an input of another height runs off the list there (TypeError); say why
         SG_REQUIRE(cfg_has_attn(c, h.H) == cfg_has_attn(c, c.image_size >> l),
                    "input height does not match the image_size the network was built for (attention placement, ncsnpp.py:308)");
         if (cfg_has_attn(c, h.H)) {
           const Mod& ma = next();
-          Tensor h2 = attn_block(ma, h, ctl);
+          g = hints_for(ma.cin);
+          Tensor h2 = attn_block(ma, h, ctl, &g);
           drop(h);
           h = h2;
         }
@@ -1484,7 +1591,8 @@ class Engine {
       }
       if (l != L - 1) {
         const Mod& m = next();
-        Tensor h = res_block(m, hs.back(), nullptr, ctl);
+        const GnHints g = hints_for(m.cout);
+        Tensor h = res_block(m, hs.back(), nullptr, ctl, &g);
         if (c.progressive_input == 1) {
           const Mod& mc = next();
           Tensor np = fir(pyr_in, false, Xform{});
@@ -1503,16 +1611,17 @@ class Engine {
 
     Tensor h = hs.back();   // not popped: still referenced by the skip stack (ncsnpp.py:337)
     {
-      const Mod& m1 = next(); Tensor a = res_block(m1, h, nullptr, ctl);
-      const Mod& m2 = next(); Tensor b2 = attn_block(m2, a, ctl); drop(a);
-      const Mod& m3 = next(); h = res_block(m3, b2, nullptr, ctl); drop(b2);
+      const Mod& m1 = next(); GnHints g = hints_for(m1.cout); Tensor a = res_block(m1, h, nullptr, ctl, &g);
+      const Mod& m2 = next(); g = hints_for(m2.cin); Tensor b2 = attn_block(m2, a, ctl, &g); drop(a);
+      const Mod& m3 = next(); g = hints_for(m3.cout); h = res_block(m3, b2, nullptr, ctl, &g); drop(b2);
     }
     Tensor pyramid; bool have_pyr = false;
     for (int l = L - 1; l >= 0; --l) {
       for (int rb = 0; rb < c.num_res_blocks + 1; ++rb) {
         const Mod& m = next();
         Tensor skip = hs.back(); hs.pop_back();
-        Tensor o = res_block(m, h, &skip, ctl);
+        const GnHints g = hints_for(m.cout);
+        Tensor o = res_block(m, h, &skip, ctl, &g);
         drop(h); drop(skip);
         h = o;
       }
@@ -1520,7 +1629,8 @@ class Engine {
                  "input height does not match the image_size the network was built for (attention placement, ncsnpp.py:354)");
       if (cfg_has_attn(c, h.H)) {
         const Mod& ma = next();
-        Tensor h2 = attn_block(ma, h, ctl);
+        const GnHints g = hints_for(ma.cin);
+        Tensor h2 = attn_block(ma, h, ctl, &g);
         drop(h); h = h2;
       }
       if (c.progressive == 1) {
@@ -1538,7 +1648,8 @@ class Engine {
       }
       if (l != 0) {
         const Mod& m = next();
-        Tensor o = res_block(m, h, nullptr, ctl);
+        const GnHints g = hints_for(m.cout);
+        Tensor o = res_block(m, h, nullptr, ctl, &g);
         drop(h); h = o;
       }
     }
@@ -1556,6 +1667,8 @@ class Engine {
       drop(h);
     }
     SG_REQUIRE(mi == layout_.size(), "forward did not consume every module");
+    SG_REQUIRE(pre_pending_ == 0, "internal: GroupNorm coefficients were prepared for a consumer that never asked for them");
+    SG_REQUIRE(dry_ || fin_next_ == fin_count_, "internal: GroupNorm tail jobs differ from the planned ones");
     if (!dry_) {
       ExitArgs ea{h4.p, Wp("output_layer.weight"), Wp("output_layer.bias"), ctl.tvals, ctl.t_bstride, ctl.t_sstride, ctl.step_ptr,
                   c.variant == 1 ? 1 : 0, c.scale_by_sigma,
@@ -1655,6 +1768,7 @@ class Engine {
     split_stagger_mode_ = e ? atoi(e) : 0;
     coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);
     poison_ = flag("SGMSE_POISON", false);
+    debug_sync_ = flag("SGMSE_DEBUG_SYNC", false);          // synchronise after every launch of the forward and print its label (stderr)
     entry_mfma_ = flag("SGMSE_ENTRY_MFMA", true);           // entry convolution on the fp32 MFMA kernel (input channels padded to 8)
     fold_shortcut_ = flag("SGMSE_FOLD_SHORTCUT", true);
     coarse_split_ = flag("SGMSE_COARSE_SPLIT", true);        // chunked 4-row fp16x2 split kernel for levels of few tiles per image
@@ -1666,6 +1780,18 @@ class Engine {
     chunk_min_width_ = e ? atoi(e) : 32;                    //     (profiles/r02_chunk_splitk.txt)
     e = getenv("SGMSE_COARSE_SPLITK_DIV");                  // ... whose chunks go to separate workgroups below tile_min_blocks / this
     coarse_splitk_div_ = e ? atol(e) : 4L;                  //     (batch 1: 0.503 -> 0.457 s per utterance, profiles/r02_chunk_splitk.txt)
+    // Work finished by the LAST workgroup to arrive instead of by a second launch -- GroupNorm coefficients in the tail of the
+    // producing convolution (conv_gn_tail), split-K reduce + epilogue by the last chunk workgroup of a tile (ConvArgs::splitk_ctr).
+    // Both are bit-identical to the two-launch form and both are OFF: an arrival needs a device-scope release in every workgroup
+    // (buffer_wbl2: each XCD has its own L2) and that costs more than the launches it saves -- batch 1: 0.457 s per utterance
+    // without, 0.478 s with the fused split-K, 0.529 s with the tails, 0.547 s with both; batch 32: 5.11 / 4.94 / 4.80 utt/s
+    // (profiles/r03_arrive_last_ab.txt; with a full fence per arrival it was 0.49 / 0.57 / 0.79 s).
+    gn_tail_ = flag("SGMSE_GN_TAIL", false);
+    splitk_fused_ = flag("SGMSE_SPLITK_FUSED", false);
+    e = getenv("SGMSE_GN_TAIL_MODE");                       // 0: release / acquire fences around plain accesses; 1 (experimental): device-coherent
+    gn_tail_mode_ = e ? atoi(e) : 0;                        //    accesses to the partial sums, no cache maintenance (ConvArgs::fin_mode)
+    e = getenv("SGMSE_GN_TAIL_MAX_PAIRS");                  // ... for tensors of at most this many partial pairs per utterance
+    gn_tail_max_pairs_ = e ? atol(e) : 8192L;
   }
   // per-forward range-bound slots ([B][kAmaxSpread] floats each), handed out in program order; counted by the dry run
   float* amax_pool_ = nullptr; size_t amax_pool_floats_ = 0; int amax_slots_ = 0, amax_next_ = 0;
@@ -1673,15 +1799,36 @@ class Engine {
     const int i = amax_next_++;
     // dry run: a fake address (never dereferenced), non-null so that the kernel-family decisions that ask "is the bound known?"
     // come out as in the real run and the arena is sized for the launches that will really happen
-    if (dry_) return reinterpret_cast<float*>(uintptr_t(1) << 43) + (size_t)i * kAmaxSpread;
+    if (dry_ && !plan_) return reinterpret_cast<float*>(uintptr_t(1) << 43) + (size_t)i * kAmaxSpread;
     SG_REQUIRE(amax_pool_ && i < amax_slots_, "range-bound pool smaller than the forward needs");
     return amax_pool_ + (size_t)i * B_ * kAmaxSpread;
+  }
+  // GroupNorm tails (conv, GnHint): the finalize jobs of one forward, in program order, on the host (written by the planning
+  // pass) and on the device (read by conv_gn_tail)
+  static constexpr int kMaxFin = 256;
+  std::vector<GnFin> fin_host_; GnFin* fin_dev_ = nullptr; int fin_next_ = 0, fin_count_ = 0, pre_pending_ = 0;
+  bool plan_ = false, gn_tail_ = false, splitk_fused_ = false; long gn_tail_max_pairs_ = 8192; int gn_tail_mode_ = 0;
+  void plan_gn_tails(int B, int F, int T) {
+    fin_host_.assign(kMaxFin, GnFin{});
+    arena_.reset();
+    dry_ = true; plan_ = true;
+    {
+      FwdCtl ctl{nullptr, 0, 0, nullptr, nullptr, 0, 0, 1.f};
+      run_forward(nullptr, 0, nullptr, 0, nullptr, B, F, T, ctl);
+    }
+    dry_ = false; plan_ = false;
+    fin_count_ = fin_next_;
+    if (fin_count_) {
+      SG_CHECK(drt::memcpy_h2d(fin_dev_, fin_host_.data(), sizeof(GnFin) * (size_t)fin_count_, stream_));
+      SG_CHECK(drt::stream_sync(stream_));
+    }
+    arena_.reset();
   }
   long tile_min_blocks_ = 512, split_min_tiles_ = 8, split_stagger_ = SGMSE_SPLIT_STAGGER_DEFAULT;
   int split_stagger_mode_ = 0;
   bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true, entry_mfma_ = true;
   ConvW entry8_{}; int entry8_idx_ = -1;
-  bool poison_ = false;
+  bool poison_ = false, debug_sync_ = false;
   long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8, chunk_min_tiles_ = 2;
   int chunk_min_width_ = 32;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;

@@ -33,6 +33,7 @@ namespace sgmse {
 // first pixel in the packed plane sets (sum over the utterances before it of H * w), soff[b] = the same prefix over its GroupNorm
 // statistics sub-tiles (H * ceil(w / 32)).  w == nullptr: every utterance has the launch's W (uniform batch).
 struct Rag { const int* w; const long long* off; const long long* soff; };
+struct GnFin;
 
 struct ConvArgs {
   const float* src1; const float* src2;  // NCHW; virtual concat [src1 | src2] along C (src2 may be null)
@@ -106,6 +107,20 @@ struct ConvArgs {
   int rag_vec_ok;             // ragged: every utterance's width is a multiple of 4 (float4 staging allowed)
   // measurement (ABL bit 6 instantiation): per workgroup {hw_id | xcc_id << 32, t_start, t_loop, t_epilogue, t_end} (shader clock)
   unsigned long long* trace;
+  // GroupNorm coefficients of this tensor's consumer(s), finished by the launch that produces the tensor (conv_gn_tail): the
+  // workgroup of an utterance that arrives LAST at the utterance's counter (fin_ctr[b * kAmaxSpread], zeroed by the engine with
+  // the range-bound pool) runs the nfin finalize jobs `fin` (device table; source 1 of each = this launch's stats_out) for that
+  // utterance -- what a gn_finalize_kernel launch behind this one would compute, bit for bit, without the launch.  Which
+  // workgroup does it varies, what it computes does not.  null: the engine launches gn_finalize_kernel itself.
+  const GnFin* fin; int nfin; unsigned* fin_ctr;
+  // fin_mode 0: the arrival is a device-scope release (every workgroup) / acquire (the last one) around plain accesses;
+  // 1 (experimental): this launch's partial sums are written and read with device-coherent accesses (drt_store_agent /
+  // drt_load_agent) and the arrival does no cache maintenance (drt_arrive_last_coherent)
+  int fin_mode;
+  // Split-K without a second launch: one arrival counter per (tile, channel block) of the launch (zeroed by the engine); the
+  // chunk workgroup of a tile that arrives LAST sums the tile's partial sums in chunk order and runs the epilogue itself -- what
+  // conv_splitk_reduce_kernel would do behind this launch, bit for bit.  null: the reduce kernel follows.
+  unsigned* splitk_ctr;
 };
 
 constexpr int kAmaxSpread = 64;
@@ -144,6 +159,15 @@ __device__ __forceinline__ float amax_read(const float* amax, int b) {
   return m;
 }
 
+template <bool COH>
+__device__ __forceinline__ float amax_read_t(const float* amax, int b) {
+  const float* q = amax + b * kAmaxSpread + (threadIdx.x & (kAmaxSpread - 1));
+  float m = COH ? drt_load_agent(q) : *q;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return m;
+}
+
 // exact power of two 2^k with m 2^k in [2^13, 2^14): the operand scale of the fp16x2 kernels for a tensor bounded by m
 __device__ __forceinline__ float h2_weight_scale(float absmax) {
   if (!(absmax > 0.f)) return 1.f;
@@ -151,6 +175,167 @@ __device__ __forceinline__ float h2_weight_scale(float absmax) {
   int k = 13 - e;
   k = k > 100 ? 100 : (k < -100 ? -100 : k);
   return __builtin_bit_cast(float, (uint32_t)(k + 127) << 23);
+}
+
+// ---- GroupNorm coefficients from partial sums (nn.GroupNorm(min(C//4,32), C, eps=1e-6), reference layerspp.py:67,219,231) --------
+// One job: scale[b][c], shift[b][c] (x * scale + shift = GroupNorm(x) with gamma/beta folded in) of the virtual concat
+// [source 1 | source 2], each source given as per-(b, c) partial {sum, sumsq} pairs (nsub per channel: 1 from gn_chan_stats_kernel,
+// the number of statistics sub-tiles when a convolution epilogue produced them), plus the range bound an fp16x2 consumer scales by
+// (bound_out, see gn_finalize_kernel).  rps: image rows per statistics sub-tile of the source (ragged launches need it).
+struct GnFin {
+  const float* st1; const float* st2; const float* amax1; const float* amax2;
+  const float* gamma; const float* beta; float* scale; float* shift; float* bound_out;
+  Rag rag;
+  int C1, nsub1, rps1, C2, nsub2, rps2, G, HW, H;
+  float eps;
+};
+
+// The canonical order of a group's sum: 256 SLOTS, slot j takes the elements j, j + 256, ... (two pairs per 16-byte load where the
+// alignment allows) of source 1's share and then of source 2's, in fp64; the slots are then summed by the tree
+// slot[t] += slot[t + m], m = 128 ... 1.  gn_finalize_kernel runs a slot per thread, gn_finalize_group_wave four slots per lane:
+// the same additions in the same order.
+__device__ __forceinline__ void gn_sum_pairs(const float* base, int n, int slot, double& s, double& q) {
+  if ((reinterpret_cast<uintptr_t>(base) & 15) == 0 && (n & 1) == 0) {
+    const float4* b4 = reinterpret_cast<const float4*>(base);
+#pragma unroll 4
+    for (int i = slot; i < n / 2; i += 256) {
+      const float4 v = b4[i];
+      s += (double)v.x + (double)v.z; q += (double)v.y + (double)v.w;
+    }
+  } else {
+    for (int i = slot; i < n; i += 256) { s += (double)base[2 * i]; q += (double)base[2 * i + 1]; }
+  }
+}
+
+// the slots lane, lane + 64, lane + 128, lane + 192 of the same order in ONE loop (slot k of this lane = accumulator k): every
+// slot still takes its elements in increasing order
+// COH: the pairs are read with device-coherent loads (ConvArgs::fin_mode 1); the additions are the same
+template <bool COH>
+__device__ __forceinline__ void gn_sum_pairs_wave(const float* base, int n, int lane, double (&s)[4], double (&q)[4]) {
+  if ((reinterpret_cast<uintptr_t>(base) & 15) == 0 && (n & 1) == 0) {
+    const float4* b4 = reinterpret_cast<const float4*>(base);
+#pragma unroll 1
+    for (int i0 = lane; i0 < n / 2; i0 += 256) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + 64 * k;
+        if (i < n / 2) {
+          float4 v;
+          if constexpr (COH) { const float* e = base + 4 * (size_t)i; v = make_float4(drt_load_agent(e), drt_load_agent(e + 1), drt_load_agent(e + 2), drt_load_agent(e + 3)); }
+          else v = b4[i];
+          s[k] += (double)v.x + (double)v.z; q[k] += (double)v.y + (double)v.w;
+        }
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int i0 = lane; i0 < n; i0 += 256) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + 64 * k;
+        if (i < n) {
+          const float a = COH ? drt_load_agent(base + 2 * i) : base[2 * i], c = COH ? drt_load_agent(base + 2 * i + 1) : base[2 * i + 1];
+          s[k] += (double)a; q[k] += (double)c;
+        }
+      }
+    }
+  }
+}
+
+struct GnGroupSpan { const float* p1; int n1; const float* p2; int n2; int HW; };
+// where the partial pairs of group g of utterance b lie (source 1 covers channels [c_lo, min(c_hi, C1)), source 2 the rest: a group
+// may straddle the concat boundary) and the utterance's pixels per plane
+__device__ __forceinline__ GnGroupSpan gn_group_span(const GnFin& f, int b, int g) {
+  const int cpg = (f.C1 + f.C2) / f.G;
+  const int c_lo = g * cpg, c_hi = c_lo + cpg;
+  int nsub1 = f.nsub1, nsub2 = f.nsub2, HW = f.HW;
+  size_t sb1 = (size_t)b * nsub1, sb2 = (size_t)b * nsub2;       // first sub-tile of utterance b, per channel-set
+  if (f.rag.w) {
+    const int w = f.rag.w[b], ns = f.H * ((w + 31) >> 5);
+    HW = f.H * w;
+    if (nsub1 > 1) { nsub1 = ns / f.rps1; sb1 = (size_t)(f.rag.soff[b] / f.rps1); }
+    if (nsub2 > 1) { nsub2 = ns / f.rps2; sb2 = (size_t)(f.rag.soff[b] / f.rps2); }
+  }
+  GnGroupSpan sp{nullptr, 0, nullptr, 0, HW};
+  const int a_hi = c_hi < f.C1 ? c_hi : f.C1;
+  if (c_lo < a_hi) { sp.p1 = f.st1 + (sb1 * f.C1 + (size_t)c_lo * nsub1) * 2; sp.n1 = (a_hi - c_lo) * nsub1; }
+  const int b_lo = c_lo > f.C1 ? c_lo : f.C1;
+  if (b_lo < c_hi) { sp.p2 = f.st2 + (sb2 * f.C2 + (size_t)(b_lo - f.C1) * nsub2) * 2; sp.n2 = (c_hi - b_lo) * nsub2; }
+  return sp;
+}
+
+// the group's totals -> coefficients of its channels (lane < cpg of ONE wave; cpg <= 64) and the group's share of the range bound.
+//     |x - mean| <= min(max|x| + |mean|, sqrt(N var))      max|x|: the producers' range bounds amax1 / amax2 (null: unknown)
+//     bound_c = that * rstd * |gamma_c| + |beta_c|,        N var = sum of squared deviations of the group (>= any single one)
+// reduced over the group's channels here and over the groups by an atomic max (order-independent: deterministic).
+template <bool COH = false>
+__device__ __forceinline__ void gn_group_coeffs(const GnFin& f, int b, int g, int lane, double s_tot, double q_tot, int HW) {
+  const int C = f.C1 + f.C2, cpg = C / f.G, c_lo = g * cpg;
+  float am = -1.f;                    // max |x| of the utterance over both sources; < 0: unknown
+  if (f.bound_out && f.amax1 && (f.C2 == 0 || f.amax2)) {        // (whole wave: amax_read shuffles)
+    am = amax_read_t<COH>(f.amax1, b);
+    if (f.C2) am = fmaxf(am, amax_read_t<COH>(f.amax2, b));
+  }
+  float bnd = 0.f;
+  if (lane < cpg) {
+    const int c = c_lo + lane;
+    const double n = (double)cpg * (double)HW;
+    const double mean = s_tot / n;
+    double var = q_tot / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float a = f.gamma[c] * rstd;
+    f.scale[(size_t)b * C + c] = a;
+    f.shift[(size_t)b * C + c] = f.beta[c] - (float)mean * a;
+    double dev = sqrt(n * var);
+    if (am >= 0.f) dev = fmin(dev, (double)am + fabs(mean));
+    bnd = (float)(dev * (double)rstd * fabs((double)f.gamma[c]) + fabs((double)f.beta[c])) * 1.0001f;   // (margin for the fp32 affine's own rounding)
+    if (!(bnd >= 0.f)) bnd = 3.0e38f;      // NaN statistics: the result is NaN whatever the scale
+  }
+  if (f.bound_out) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, o));
+    if (lane == 0) drt_atomic_max_nonneg(f.bound_out + b * kAmaxSpread + (g & (kAmaxSpread - 1)), bnd);
+  }
+}
+
+// one group by ONE wave: lane l runs the slots l, l + 64, l + 128, l + 192 of the canonical order (one loop, few registers: the
+// tail must stay below the register count of the smallest convolution kernel it is inlined into); the tree's levels 128 and 64
+// are adds inside the lane, the levels 32 ... 1 an xor butterfly (a + b = b + a: every lane ends with the tree's value)
+template <bool COH>
+__device__ __forceinline__ void gn_finalize_group_wave(const GnFin& f, int b, int g, int lane) {
+  const GnGroupSpan sp = gn_group_span(f, b, g);
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+  if (sp.n1) gn_sum_pairs_wave<COH>(sp.p1, sp.n1, lane, s, q);
+  if (sp.n2) gn_sum_pairs_wave<COH>(sp.p2, sp.n2, lane, s, q);
+  s[0] += s[2]; q[0] += q[2]; s[1] += s[3]; q[1] += q[3];      // m = 128
+  s[0] += s[1]; q[0] += q[1];                                  // m = 64
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { s[0] += drt_shfl_xor_f64(s[0], m); q[0] += drt_shfl_xor_f64(q[0], m); }
+  gn_group_coeffs<COH>(f, b, g, lane, s[0], q[0], sp.HW);
+}
+
+// Tail of a statistics-producing launch (ConvArgs::fin): the last workgroup of utterance b finishes the consumers' GroupNorm
+// coefficients.  Called by the whole workgroup, also by workgroups that have nothing else to do (ragged tiles beyond the
+// utterance's width): they count.  Every launch that reaches this lays its grid out as (tiles of the B utterances, channel
+// blocks): gridDim.x / B * gridDim.y workgroups per utterance.
+__device__ __forceinline__ void conv_gn_tail(const ConvArgs& p, int b) {
+  if (!p.fin) return;                                          // uniform
+  const unsigned per_utt = gridDim.x / (unsigned)p.B * gridDim.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (int)(blockDim.x >> 6);
+  if (p.fin_mode == 1) {
+    if (!drt_arrive_last_coherent(p.fin_ctr + b * kAmaxSpread, per_utt)) return;
+    for (int k = 0; k < p.nfin; ++k) {
+      const GnFin f = p.fin[k];
+      for (int g = wave; g < f.G; g += nw) gn_finalize_group_wave<true>(f, b, g, lane);
+    }
+    return;
+  }
+  if (!drt_arrive_last(p.fin_ctr + b * kAmaxSpread, per_utt)) return;
+  for (int k = 0; k < p.nfin; ++k) {
+    const GnFin f = p.fin[k];
+    for (int g = wave; g < f.G; g += nw) gn_finalize_group_wave<false>(f, b, g, lane);
+  }
 }
 
 // SiLU x*sigmoid(x) (nn.SiLU, reference layers.py:38-39) on the hardware exp2/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each,
@@ -358,12 +543,12 @@ __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&
           st2 = (j & 3) == 0 ? e2 : st2 + e2;
           if (((j & 3) == 3 || (GUARD && y + 1 >= H)) && (!GUARD || co < p.Cout)) {
             float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)(y >> 2) * tiles_x + tx) * 2;
-            so[0] = st1; so[1] = st2;
+            if (p.fin_mode == 1) { drt_store_agent(so, st1); drt_store_agent(so + 1, st2); } else { so[0] = st1; so[1] = st2; }
           }
         } else {
           if (!GUARD || co < p.Cout) {
             float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)y * tiles_x + tx) * 2;
-            so[0] = e1; so[1] = e2;
+            if (p.fin_mode == 1) { drt_store_agent(so, e1); drt_store_agent(so + 1, e2); } else { so[0] = e1; so[1] = e2; }
           }
         }
       }
@@ -404,6 +589,55 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
   }
 }
 
+// Second half of a split-K convolution: the chunks' partial sums, summed in chunk order into the accumulator layout of the
+// producing tile shape (elements outside the tensor: 0).  Used by conv_splitk_reduce_kernel and by the chunk kernels' own last
+// workgroup (ConvArgs::splitk_ctr).
+template <class T, int FC, int FP, int WC>
+__device__ __forceinline__ void conv_splitk_sum(const ConvArgs& p, int nchunks, int b, int co_blk, int tx, int ty, int wc, int wp,
+                                                int l31, int kh, f32x16 (&acc)[FC][FP]) {
+  constexpr int ROWS = T::ROWS, CO_T = T::CO_T;
+  const int H = p.H, W = p.W;
+  const size_t slab = conv_partial_slab(p, H, W);
+  const int x = tx * 32 + l31;
+  // chunk loop OUTSIDE: the FC*FP*16 loads of one chunk are independent and in flight together; an element still sums its
+  // chunks in chunk order (what makes split-K bit-identical to the chunked single-workgroup run)
+  for (int z = 0; z < nchunks; ++z) {
+    const float* pz = p.partial + (size_t)z * slab;
+    f32x16 v[FC][FP];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+      for (int j = 0; j < FP; ++j) {
+        const int y = ty * ROWS + wp * FP + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+          const bool ok = co < p.Cout && y < H && x < W;
+          v[i][j][r] = pz[ok ? ((size_t)(b * p.Cout + co) * H + y) * W + x : 0];      // clamped, unpredicated
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);      // (left alone the compiler runs load - wait - add through ONE register, 16*FC*FP round trips)
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+      for (int j = 0; j < FP; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = z == 0 ? v[i][j][r] : acc[i][j][r] + v[i][j][r];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < FC; ++i)
+#pragma unroll
+    for (int j = 0; j < FP; ++j) {
+      const int y = ty * ROWS + wp * FP + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+        if (!(co < p.Cout && y < H && x < W)) acc[i][j][r] = 0.f;
+      }
+    }
+}
+
 // PREF = 1: the LDS operand reads of k-step s+1 are issued before the MFMAs of k-step s (order pinned with
 //           sched_group_barrier), so a wave does not park on lgkmcnt between MFMA groups.  PREF = 0: compiler order.
 // VEC  = 1: float4 input staging (needs W % 4 == 0 and 16-byte aligned sources); 0: element-wise staging.
@@ -425,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
   const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
   const int tiles_x = (p.W + 31) >> 5;
   const int x0 = tx * 32, y0 = ty * ROWS;
   const int co_blk = blockIdx.y;
@@ -678,6 +912,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
       q.out = p.partial + (size_t)blockIdx.z * conv_partial_slab(p, H, W);
       q.bias = nullptr; q.bias2 = nullptr; q.res = nullptr; q.acc_scale = nullptr; q.out_scale = 1.f; q.stats_out = nullptr; q.amax_out = nullptr;
       conv_epilogue<T, FC, FP, WC>(q, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
+      if (!p.splitk_ctr) return;                       // conv_splitk_reduce_kernel follows
+      if (!drt_arrive_last(p.splitk_ctr + blockIdx.y * gridDim.x + blockIdx.x, gridDim.z)) return;
+      conv_splitk_sum<T, FC, FP, WC>(p, (int)gridDim.z, b, co_blk, tx, ty, wc, wp, l31, kh, acc);
+      conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
+      conv_gn_tail(p, b);
       return;
     }
   } else {
@@ -693,6 +932,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
   }
 
   conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
+  conv_gn_tail(p, b);
 }
 
 // Second half of a split-K convolution (ConvArgs::kchunk_stages): sums the chunks' partial sums in chunk order into the
@@ -709,56 +949,19 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
   const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
   const int wc = wave % WC, wp = wave / WC;
-  const size_t slab = conv_partial_slab(p, H, W);
-  const int x = tx * 32 + l31;
   f32x16 acc[FC][FP];
-  // chunk loop OUTSIDE: the FC*FP*16 loads of one chunk are independent and in flight together; an element still sums its
-  // chunks in chunk order (what makes split-K bit-identical to the chunked single-workgroup run)
-  for (int z = 0; z < nchunks; ++z) {
-    const float* pz = p.partial + (size_t)z * slab;
-    f32x16 v[FC][FP];
-#pragma unroll
-    for (int i = 0; i < FC; ++i)
-#pragma unroll
-      for (int j = 0; j < FP; ++j) {
-        const int y = ty * ROWS + wp * FP + j;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
-          const bool ok = co < p.Cout && y < H && x < W;
-          v[i][j][r] = pz[ok ? ((size_t)(b * p.Cout + co) * H + y) * W + x : 0];      // clamped, unpredicated
-        }
-      }
-    __builtin_amdgcn_sched_barrier(0);      // (left alone the compiler runs load - wait - add through ONE register, 16*FC*FP round trips)
-#pragma unroll
-    for (int i = 0; i < FC; ++i)
-#pragma unroll
-      for (int j = 0; j < FP; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = z == 0 ? v[i][j][r] : acc[i][j][r] + v[i][j][r];
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int i = 0; i < FC; ++i)
-#pragma unroll
-    for (int j = 0; j < FP; ++j) {
-      const int y = ty * ROWS + wp * FP + j;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
-        if (!(co < p.Cout && y < H && x < W)) acc[i][j][r] = 0.f;
-      }
-    }
+  conv_splitk_sum<T, FC, FP, WC>(p, nchunks, b, co_blk, tx, ty, wc, wp, l31, kh, acc);
   // chunks of the fp16x2 kernel carry its per-utterance input scale (ConvArgs::xbound); the fp32 kernels' chunks carry none
   float as_mul = 1.0f;
   if (p.xbound) as_mul = 1.0f / h2_weight_scale(amax_read(p.xbound, b));
   conv_epilogue<T, FC, FP, WC, 0, false, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as_mul);
+  conv_gn_tail(p, b);
 }
 
 // Direct (VALU) convolution: one thread per output pixel, CG output channels per thread.

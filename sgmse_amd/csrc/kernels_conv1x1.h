@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs p) {
   const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs p) {
   }
 
   conv_epilogue<T, FC, FP, 1>(p, acc, b, co_blk, tx, ty, tiles_x, 0, wave, l31, kh);
+  conv_gn_tail(p, b);
 }
 
 }  // namespace sgmse

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
@@ -632,6 +632,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       if (st + 1 < nst) thin_stage(st + 1, s_in1, s_in0, rin2);
     }
     conv_epilogue<T, FCW, FPW, WCW, 0, true, false>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
+    conv_gn_tail(p, b);
     return;
   }
   constexpr int AR = 3, AD = AR - 1;
@@ -699,7 +700,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       q.out = p.partial + (size_t)blockIdx.z * conv_partial_slab(p, H, W);
       q.bias = nullptr; q.bias2 = nullptr; q.res = nullptr; q.acc_scale = nullptr; q.out_scale = 1.f; q.stats_out = nullptr; q.amax_out = nullptr;
       conv_epilogue<T, FCW, FPW, WCW, 0, true>(q, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg);
-      return;
+      if (!p.splitk_ctr) return;                     // conv_splitk_reduce_kernel follows
+      if (!drt_arrive_last(p.splitk_ctr + blockIdx.y * gridDim.x + blockIdx.x, gridDim.z)) return;
+      conv_splitk_sum<T, FCW, FPW, WCW>(p, (int)gridDim.z, b, co_blk, tx, ty, wc, wp, l31, kg, acc);
+      // (falls through to the epilogue of the single-workgroup run: bias terms, residual, scale, statistics, range bound)
     }
   }
   if constexpr (ABL & 64) {
@@ -711,6 +715,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
 
   if constexpr (ABL & 64) { if (trace) trace[3] = drt_clock(); }
   conv_epilogue<T, FCW, FPW, WCW, ABL & (3 | 128 | 256), !CHK, FPW % 4 == 0>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
+  conv_gn_tail(p, b);
   if constexpr (ABL & 64) { if (trace) trace[4] = drt_clock(); }
 }
 
@@ -741,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
   const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
@@ -874,6 +879,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
   }
 
   conv_epilogue<T, 1, 8, 4, 0, false, true>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg, 1.0f / xs);
+  conv_gn_tail(p, b);
 }
 
 }  // namespace sgmse

@@ -53,93 +53,34 @@ __global__ __launch_bounds__(256) void gn_chan_stats_kernel(const float* src1, c
   }
 }
 
-// this thread's share of n {sum, sumsq} pairs: two pairs per 16-byte load, four loads in flight (the partials of the full-
-// resolution levels are 4096 pairs per channel: issued one dependent 4-byte load at a time this was 20 us of latency per
-// GroupNorm at batch 1).  Fixed thread -> element map: deterministic.
-__device__ __forceinline__ void gn_sum_pairs(const float* base, int n, double& s, double& q) {
-  if ((reinterpret_cast<uintptr_t>(base) & 15) == 0 && (n & 1) == 0) {
-    const float4* b4 = reinterpret_cast<const float4*>(base);
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n / 2; i += 256) {
-      const float4 v = b4[i];
-      s += (double)v.x + (double)v.z; q += (double)v.y + (double)v.w;
-    }
-  } else {
-    for (int i = threadIdx.x; i < n; i += 256) { s += (double)base[2 * i]; q += (double)base[2 * i + 1]; }
-  }
-}
-
 // Per-(b,c) totals come as `nsub` partial {sum, sumsq} pairs per channel (nsub = 1 from gn_chan_stats_kernel, the number
 // of statistics sub-tiles when a convolution epilogue produced them); the two sources of a virtual concat may differ.
 // grid = (G, B): one workgroup per group.  The partials of a group's channels are contiguous per source, so the 256 threads
-// stream them coalesced (fixed thread -> element map and a fixed fp64 tree: deterministic), then thread c < cpg writes the
-// folded coefficients of channel g*cpg + c.
+// stream them coalesced (the canonical slot order and fp64 tree of gn_sum_pairs, kernels_conv.h: deterministic), then lane c < cpg
+// of wave 0 writes the folded coefficients of channel g*cpg + c.  The same job runs, with the same additions in the same order,
+// in the tail of the producing convolution when the engine asks for that (conv_gn_tail): this kernel is the path of the tensors
+// whose partials are too many for one workgroup per utterance, or that no convolution epilogue produced.
 // Ragged launch (rag.w): utterance b has H * rag.w[b] pixels per plane; a source whose partials come from a convolution
 // epilogue (nsub > 1) holds them packed per utterance -- (H / rps) * ceil(w / 32) sub-tiles per channel from sub-tile rag.soff[b] / rps on,
 // exactly the layout of the utterance's own launch; gn_chan_stats sources (nsub == 1) are one pair per (b, c) either way.
 // Range bound for an fp16x2 consumer (bound_out, [B][kAmaxSpread], zeroed by the engine; null: not wanted): an upper bound of
-// |x * scale + shift| -- and with it of its SiLU, |silu(t)| <= |t| -- over the utterance, from the utterance's own data:
-//     |x - mean| <= min(max|x| + |mean|, sqrt(N var))      max|x|: the producers' range bounds amax1 / amax2 (null: unknown)
-//     bound_c = that * rstd * |gamma_c| + |beta_c|,        N var = sum of squared deviations of the group (>= any single one)
-// reduced over the group's channels here and over the groups by an atomic max (order-independent: deterministic).
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* st1, int C1, int nsub1, const float* st2, int C2, int nsub2,
-                                                          const float* gamma, const float* beta, int G, int HW, float eps,
-                                                          float* scale, float* shift, Rag rag, int H,
-                                                          const float* amax1, const float* amax2, float* bound_out, int rps1, int rps2) {
+// |x * scale + shift| -- and with it of its SiLU, |silu(t)| <= |t| -- over the utterance, from the utterance's own data
+// (gn_group_coeffs).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GnFin f) {
   __shared__ double s_s[256];
   __shared__ double s_q[256];
-  const int g = blockIdx.x, b = blockIdx.y, C = C1 + C2, cpg = C / G;
-  const int c_lo = g * cpg, c_hi = c_lo + cpg;
-  size_t sb1 = (size_t)b * nsub1, sb2 = (size_t)b * nsub2;       // first sub-tile of utterance b, per channel-set
-  if (rag.w) {
-    // rps: image rows per statistics sub-tile of the source (1, or 4 for tensors the split kernels produced; H % 4 == 0 then)
-    const int w = rag.w[b], ns = H * ((w + 31) >> 5);
-    HW = H * w;
-    if (nsub1 > 1) { nsub1 = ns / rps1; sb1 = (size_t)(rag.soff[b] / rps1); }
-    if (nsub2 > 1) { nsub2 = ns / rps2; sb2 = (size_t)(rag.soff[b] / rps2); }
-  }
+  const int g = blockIdx.x, b = blockIdx.y;
+  const GnGroupSpan sp = gn_group_span(f, b, g);
   double s = 0.0, q = 0.0;
-  // source 1 covers channels [c_lo, min(c_hi, C1)), source 2 the rest (a group may straddle the concat boundary)
-  const int a_hi = c_hi < C1 ? c_hi : C1;
-  if (c_lo < a_hi) {
-    gn_sum_pairs(st1 + (sb1 * C1 + (size_t)c_lo * nsub1) * 2, (a_hi - c_lo) * nsub1, s, q);
-  }
-  const int b_lo = c_lo > C1 ? c_lo : C1;
-  if (b_lo < c_hi) {
-    gn_sum_pairs(st2 + (sb2 * C2 + (size_t)(b_lo - C1) * nsub2) * 2, (c_hi - b_lo) * nsub2, s, q);
-  }
+  if (sp.n1) gn_sum_pairs(sp.p1, sp.n1, threadIdx.x, s, q);
+  if (sp.n2) gn_sum_pairs(sp.p2, sp.n2, threadIdx.x, s, q);
   s_s[threadIdx.x] = s; s_q[threadIdx.x] = q;
   __syncthreads();
   for (int m = 128; m >= 1; m >>= 1) {
     if ((int)threadIdx.x < m) { s_s[threadIdx.x] += s_s[threadIdx.x + m]; s_q[threadIdx.x] += s_q[threadIdx.x + m]; }
     __syncthreads();
   }
-  float am = -1.f;                    // max |x| of the utterance over both sources; < 0: unknown
-  if (bound_out && amax1 && (C2 == 0 || amax2)) {        // (whole waves: amax_read shuffles)
-    am = amax_read(amax1, b);
-    if (C2) am = fmaxf(am, amax_read(amax2, b));
-  }
-  float bnd = 0.f;
-  if ((int)threadIdx.x < cpg) {
-    const int c = c_lo + threadIdx.x;
-    const double n = (double)cpg * (double)HW;
-    const double mean = s_s[0] / n;
-    double var = s_q[0] / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float a = gamma[c] * rstd;
-    scale[(size_t)b * C + c] = a;
-    shift[(size_t)b * C + c] = beta[c] - (float)mean * a;
-    double dev = sqrt(n * var);
-    if (am >= 0.f) dev = fmin(dev, (double)am + fabs(mean));
-    bnd = (float)(dev * (double)rstd * fabs((double)gamma[c]) + fabs((double)beta[c])) * 1.0001f;   // (margin for the fp32 affine's own rounding)
-    if (!(bnd >= 0.f)) bnd = 3.0e38f;      // NaN statistics: the result is NaN whatever the scale
-  }
-  if (bound_out && threadIdx.x < 64) {     // cpg <= 64: the group's channels sit in wave 0
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, o));
-    if (threadIdx.x == 0) drt_atomic_max_nonneg(bound_out + b * kAmaxSpread + (g & (kAmaxSpread - 1)), bnd);
-  }
+  if (threadIdx.x < 64) gn_group_coeffs(f, b, g, threadIdx.x, s_s[0], s_q[0], sp.HW);      // cpg <= 64: the group's channels sit in wave 0
 }
 
 // op-level entry points / micro-benchmarks: the bound gn_finalize_kernel would have left for a producer given as explicit

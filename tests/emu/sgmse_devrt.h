@@ -110,6 +110,32 @@ static inline float atomicAdd(float* p, float v) {
 }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+// arrival counter of a last-workgroup reduction (see sgmse_amd/csrc/sgmse_devrt.h); workgroups run on a pool of OS threads here
+static inline bool drt_arrive_last(unsigned* ctr, unsigned expected) {
+  __shared__ unsigned s_arrive_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_arrive_last = (atomicAdd(ctr, 1u) == expected - 1u) ? 1u : 0u;
+  __syncthreads();
+  const bool last = s_arrive_last != 0u;
+  if (last) __threadfence();
+  return last;
+}
+static inline void drt_store_agent(float* p, float v) { *p = v; }
+static inline float drt_load_agent(const float* p) { return *p; }
+static inline bool drt_arrive_last_coherent(unsigned* ctr, unsigned expected) { return drt_arrive_last(ctr, expected); }
+static inline double drt_shfl_xor_f64(double v, int mask) {
+  uint64_t u; memcpy(&u, &v, 8);
+  uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
+  float fl, fh; memcpy(&fl, &lo, 4); memcpy(&fh, &hi, 4);
+  fl = emu::shfl_xor(fl, mask); fh = emu::shfl_xor(fh, mask);
+  memcpy(&lo, &fl, 4); memcpy(&hi, &fh, 4);
+  u = ((uint64_t)hi << 32) | lo; memcpy(&v, &u, 8);
+  return v;
+}
+
 static inline void drt_wave_sync() { (void)emu::shfl_idx(0.f, 0); }
 #define DRT_PIN_HERE(x) ((void)0)
 #define DRT_CODE_MARKER(n) ((void)0)

@@ -244,6 +244,47 @@ def check_split_workgroup_shapes_bitwise(dev, name="fwd_nf128"):
     assert rel_l2(outs[0], torch.from_numpy(z["out"])) < NET_TOL
 
 
+def check_gn_tail_bitwise(dev, name="fwd_nf128", batch=None):
+    """Work finished by the LAST workgroup to arrive instead of by a second launch: GroupNorm coefficients in the tail of the
+    producing convolution (last workgroup of each utterance, ConvArgs::fin) vs gn_finalize_kernel launches, and the split-K
+    reduce + epilogue by the last chunk workgroup of each tile (ConvArgs::splitk_ctr) vs conv_splitk_reduce_kernel launches.
+    The same additions in the same order, so not one bit of the network's output may differ -- with the default size limit of
+    the tails (the coarse levels only) and with every eligible GroupNorm in a tail."""
+    cfg = NET_CASES[name]
+    z = load(name)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    if batch is not None:
+        x, t = x[:batch], t[:batch]
+    keys = ("SGMSE_GN_TAIL", "SGMSE_GN_TAIL_MAX_PAIRS", "SGMSE_SPLITK_FUSED", "SGMSE_GN_TAIL_MODE")
+    old = {k: os.environ.get(k) for k in keys}
+    outs, jobs = [], []
+    try:
+        # (tails, size limit, fused split-K, arrival: 0 release / acquire fences, 1 device-coherent accesses without cache maintenance)
+        for tail, pairs, fused, mode in (("0", None, "0", "0"), ("1", None, "1", "0"), ("1", "1000000000", "1", "0"), ("0", None, "1", "0"),
+                                         ("1", None, "0", "0"), ("1", None, "0", "1"), ("1", "1000000000", "1", "1")):
+            os.environ["SGMSE_GN_TAIL"] = tail
+            os.environ["SGMSE_SPLITK_FUSED"] = fused
+            os.environ["SGMSE_GN_TAIL_MODE"] = mode
+            if pairs is None:
+                os.environ.pop("SGMSE_GN_TAIL_MAX_PAIRS", None)
+            else:
+                os.environ["SGMSE_GN_TAIL_MAX_PAIRS"] = pairs
+            net, _ = make_backbone(cfg, dev)
+            outs.append(net(x.to(dev), t.to(dev)).cpu())
+            jobs.append(net.engine(torch.device(dev)).gn_tail_jobs())
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    print(f"{name} on {dev}: GroupNorm jobs in convolution tails: off {jobs[0]}, default limit {jobs[1]}, no limit {jobs[2]}")
+    assert jobs[0] == 0 and jobs[3] == 0 and jobs[1] > 0 and jobs[2] >= jobs[1] and jobs[4] == jobs[1] and jobs[5] == jobs[1] and jobs[6] == jobs[2], jobs
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    assert rel_l2(outs[0], torch.from_numpy(z["out"])[:len(x)]) < NET_TOL
+
+
 def adversarial_params(cfg, kind, seed=0):
     """Synthetic state dicts that stress the range handling of the fp16x2 / bf16x3 kernels (no real checkpoint is reachable
     offline): every kind must keep the network-level gate of the ordinary fixtures.

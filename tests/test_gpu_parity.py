@@ -463,6 +463,13 @@ def test_split_k_of_the_coarse_levels_never_changes_a_bit(hip):
     P.check_tile_independence(hip, "fwd_nf128")
 
 
+@pytest.mark.parametrize("name", ["fwd_nf32", "fwd_nf128"])
+def test_groupnorm_coefficients_in_the_convolution_tail_never_change_a_bit(hip, name):
+    """GroupNorm coefficients finished by the last workgroup of each utterance in the producing launch (device-scope release /
+    acquire around an arrival counter) vs gn_finalize_kernel launches: bit-identical network output, batch of fixtures."""
+    P.check_gn_tail_bitwise(hip, name)
+
+
 @pytest.mark.parametrize("every_layer_split", [False, True])
 def test_results_do_not_depend_on_what_device_memory_held(hip, every_layer_split):
     P.check_poison_independence(hip, "fwd_nf128", every_layer_split)
@@ -476,6 +483,12 @@ def test_sampler_does_not_depend_on_what_device_memory_held(hip, monkeypatch):
 def test_ragged_batch_gives_every_utterance_its_single_run_bits(hip):
     """Full width, frame counts from 64 to 512 in one batch: forward, PC, corrector-free PC and PF-ODE samplers (captured graph)."""
     P.check_ragged_batch(hip, "fwd_nf128", frames=(512, 64, 192, 320, 128))
+
+
+def test_ragged_batches_through_the_other_variants_and_entry_points(hip):
+    """ncsnpp_v2 with the new-code score wrapper, ncsnpp_48k, the minibatch wrappers over ragged lists and ScoreModel.enhance_batch
+    with waveforms of different lengths: every utterance keeps the bits of its own run (captured graphs on the GPU)."""
+    P.check_ragged_variants(hip)
 
 
 def test_enhancement_script_directory_to_directory(hip, tmp_path, monkeypatch):
