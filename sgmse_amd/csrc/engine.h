@@ -1293,7 +1293,7 @@ class Engine {
     // (not in ragged launches: the full-width five-utterance case of test_ragged_batch_gives_every_utterance_its_single_run_bits
     // faulted on the GPU with the tails on -- at the 4 x 8 level, utterance widths 8 / 1 / 3 / 5 / 2 -- while the same composition
     // runs clean on the emulator under AddressSanitizer; unresolved, and the mechanism is off by default anyway)
-    if (hints && gn_tail_ && !ragged() && o.st && o.nsub >= 1 && use_mfma) {
+    if (hints && gn_tail_ && !ragged() && o.st && o.nsub >= 1 && use_mfma && !(use_split && w.ks == 1)) {   // (conv1x1_split_kernel has no tail)
       for (int k = 0; k < hints->n; ++k) {
         const GnHint& hn = hints->h[k];
         const Tensor* hb = hn.b;
@@ -1323,10 +1323,8 @@ class Engine {
     // split-K: one arrival counter per (tile, channel block); the last chunk workgroup of a tile reduces and finishes it
     // (ConvArgs::splitk_ctr) instead of a conv_splitk_reduce_kernel launch
     unsigned* splitk_ctr = nullptr;
-    if (ksplit > 1 && splitk_fused_) {
-      const int co_blk = coarse_split ? 128 : co_t;
-      const int rows = coarse_split ? 4 : rows_;
-      const long nctr = (long)B_ * ((a.H + rows - 1) / rows) * ((a.W + 31) / 32) * ((w.cout + co_blk - 1) / co_blk);
+    if (ksplit > 1 && splitk_fused_ && !coarse_split) {        // (the fp32 kernels' small tiles; the chunked fp16x2 kernel keeps its reduce launch)
+      const long nctr = (long)B_ * ((a.H + rows_ - 1) / rows_) * ((a.W + 31) / 32) * ((w.cout + co_t - 1) / co_t);
       splitk_ctr = reinterpret_cast<unsigned*>(next_amax());
       for (long have = (long)B_ * kAmaxSpread; have < nctr; have += (long)B_ * kAmaxSpread) (void)next_amax();   // (consecutive slots are contiguous)
     }
@@ -1782,10 +1780,12 @@ class Engine {
     coarse_splitk_div_ = e ? atol(e) : 4L;                  //     (batch 1: 0.503 -> 0.457 s per utterance, profiles/r02_chunk_splitk.txt)
     // Work finished by the LAST workgroup to arrive instead of by a second launch -- GroupNorm coefficients in the tail of the
     // producing convolution (conv_gn_tail), split-K reduce + epilogue by the last chunk workgroup of a tile (ConvArgs::splitk_ctr).
-    // Both are bit-identical to the two-launch form and both are OFF: an arrival needs a device-scope release in every workgroup
-    // (buffer_wbl2: each XCD has its own L2) and that costs more than the launches it saves -- batch 1: 0.457 s per utterance
-    // without, 0.478 s with the fused split-K, 0.529 s with the tails, 0.547 s with both; batch 32: 5.11 / 4.94 / 4.80 utt/s
-    // (profiles/r03_arrive_last_ab.txt; with a full fence per arrival it was 0.49 / 0.57 / 0.79 s).
+    // Both are bit-identical to the two-launch form and both are OFF: the dependent step costs more as a serial tail of ONE
+    // workgroup (8 GroupNorm groups per wave, each loads -> fp64 tree -> sqrt / divide -> stores: ~ +19 us on the launch) than as
+    // a launch of its own, 32 workgroups wide (7.7 us) -- whatever the arrival does to the caches.  Batch 1: 0.4565 s per
+    // utterance without, 0.478 s with the fused split-K, 0.529 s with the tails, 0.547 s with both (release per workgroup,
+    // acquire in the last); 0.543 vs 0.472 s with device-coherent accesses and no cache maintenance (SGMSE_GN_TAIL_MODE=1); batch
+    // 32: 5.11 / 4.94 / 4.80 utt/s (profiles/r03_arrive_last_ab.txt, r03_tail_mode1_ab.txt).
     gn_tail_ = flag("SGMSE_GN_TAIL", false);
     splitk_fused_ = flag("SGMSE_SPLITK_FUSED", false);
     e = getenv("SGMSE_GN_TAIL_MODE");                       // 0: release / acquire fences around plain accesses; 1 (experimental): device-coherent

@@ -511,10 +511,13 @@ __global__ __launch_bounds__(256) void sampler_sb_kernel(SamplerArgs p) {
   const float wp = tb[SB_WPREV], we = tb[SB_WEST], wy = tb[SB_WY], wz = tb[SB_WZ];
   const float2 xv = p.x[i], ev = p.score[i], yv = p.y[i];
   // The reference's rounding sequence, product by product and sum by sum (sampling/__init__.py:200-206, 226-233: torch evaluates
-  // w_prev*xt, w_est*est, their sum, w_y*y (or w_z*z), the sum), WITHOUT fused multiply-adds: the ODE's first step is
-  // x = 5457.15 y + 0.446 est - 5456.54 y (k = 2.6, c = 0.4, N = 4; x_0 = y), a cancellation of 4 digits, so a differently
-  // rounded sum is off by ~3e-4 |y| there -- what put the 'ode' sampler at 7.3e-5 of the reference's output in round 2 while
-  // the CPU oracle, which shares torch's sequence, sat at 9.6e-6.
+  // w_prev*xt, w_est*est, their sum, w_y*y (or w_z*z), the sum), WITHOUT fused multiply-adds.  The ODE's first step is
+  // x = 5457.15 y + 0.446 est - 5456.54 y (k = 2.6, c = 0.4, N = 4; x_0 = y): the estimate is added to a number ~5457 |y| and
+  // thereby quantised to that number's ulp, 4.6e-4 |y|, before the cancellation.  Following the sequence makes this step a
+  // function of `est` alone -- it does NOT bring the sampler closer to the reference's output (measured: 7.3e-5 before and
+  // after): two implementations whose network outputs differ by a relative delta disagree by ~sqrt(delta * 0.45 * 4.6e-4) after
+  // this step, a property of the reference's algorithm in fp32 (tools/sb_conditioning.py, profiles/r03_sb_conditioning.txt:
+  // delta 1e-6 -> 1.2e-5, 1e-5 -> 3.5e-5, 3e-5 -> 6.7e-5; the CPU oracle itself is at 9.6e-6 of the reference).
   float2 r = make_float2(drt_add_rn(drt_add_rn(drt_mul_rn(wp, xv.x), drt_mul_rn(we, ev.x)), drt_mul_rn(wy, yv.x)),
                          drt_add_rn(drt_add_rn(drt_mul_rn(wp, xv.y), drt_mul_rn(we, ev.y)), drt_mul_rn(wy, yv.y)));
   if (p.add_noise) {

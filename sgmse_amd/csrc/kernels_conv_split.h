@@ -700,10 +700,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       q.out = p.partial + (size_t)blockIdx.z * conv_partial_slab(p, H, W);
       q.bias = nullptr; q.bias2 = nullptr; q.res = nullptr; q.acc_scale = nullptr; q.out_scale = 1.f; q.stats_out = nullptr; q.amax_out = nullptr;
       conv_epilogue<T, FCW, FPW, WCW, 0, true>(q, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg);
-      if (!p.splitk_ctr) return;                     // conv_splitk_reduce_kernel follows
-      if (!drt_arrive_last(p.splitk_ctr + blockIdx.y * gridDim.x + blockIdx.x, gridDim.z)) return;
-      conv_splitk_sum<T, FCW, FPW, WCW>(p, (int)gridDim.z, b, co_blk, tx, ty, wc, wp, l31, kg, acc);
-      // (falls through to the epilogue of the single-workgroup run: bias terms, residual, scale, statistics, range bound)
+      // (conv_splitk_reduce_kernel follows.  The in-launch reduce of the fp32 kernels, ConvArgs::splitk_ctr, is not built into
+      // this kernel: with the chunk sums' 64 extra registers it spilled -- 217 -> 256 VGPRs + 37 spilled -- for a mechanism that
+      // measured slower anyway, profiles/r03_arrive_last_ab.txt)
+      return;
     }
   }
   if constexpr (ABL & 64) {
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
   const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }      // (no GroupNorm tail in this kernel: its launches in the network emit no statistics)
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
@@ -879,7 +879,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
   }
 
   conv_epilogue<T, 1, 8, 4, 0, false, true>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg, 1.0f / xs);
-  conv_gn_tail(p, b);
 }
 
 }  // namespace sgmse

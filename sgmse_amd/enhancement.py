@@ -114,7 +114,7 @@ def _load_normalised(path: str, target_sr: int) -> Tuple[torch.Tensor, float]:
     return torch.from_numpy(y / peak), peak
 
 
-RAGGED_COST = 1.16          # GPU time per frame of a ragged batch relative to a uniform one (profiles/r02_ragged_bench.txt)
+RAGGED_COST = 1.16          # GPU time per frame of a ragged batch relative to a uniform one (profiles/r02_ragged_bench.txt; 1.15 in r03_ragged_bench.txt)
 
 
 def probe_samples(path: str, target_sr: int) -> int:

@@ -14,7 +14,7 @@ import json
 d=json.loads(open('$1').read().strip().splitlines()[-1]); print('$2', round(d['value'],4), 'utt/s', round(d['ms_per_step'],1), 'ms/step', 'tail jobs', d.get('gn_tail_jobs_per_eval'))" 2>/dev/null || echo "$2 FAILED"; }
 rocm-smi --showproductname 2>/dev/null | head -8 > $O/gpu.txt; nproc >> $O/gpu.txt
 if has smoke; then echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -2 | tee $O/r03_smoke.txt; fi
-if has pytest; then echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $O/r03_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/r03_pytest_gpu.log | cut -c1-300; grep -E "GroupNorm jobs|Memory access" $O/r03_pytest_gpu.log; fi
+if has pytest; then echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -q -s -p no:cacheprovider ${PYTEST_K:+-k "$PYTEST_K"} > $O/r03_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/r03_pytest_gpu.log | cut -c1-300; grep -E "GroupNorm jobs|Memory access" $O/r03_pytest_gpu.log; fi
 if has bench; then echo "== bench (driver defaults)"; timeout 900 python bench.py > $O/r03_bench_b32.json 2>$O/r03_bench.err; echo "bench rc=$?"; cut -c1-700 $O/r03_bench_b32.json; tail -2 $O/r03_bench.err; fi
 if has rocprof; then
   echo "== rocprofv3 kernel trace of the bench command"
