@@ -1332,6 +1332,7 @@ class Engine {
     ConvArgs ca{};
     ca.fin = fin_dev; ca.nfin = nfin; ca.fin_ctr = reinterpret_cast<unsigned*>(fin_ctr); ca.fin_mode = nfin ? gn_tail_mode_ : 0;
     ca.splitk_ctr = splitk_ctr;
+    ca.xcd_map = conv_xcd_map_ ? 1 : 0;
     ca.stats_out = o.st; ca.stats_nsub = o.nsub; ca.stats_rows = o.srows;
     ca.amax_out = o.amax;
     ca.src1 = a.p; ca.src2 = b ? b->p : nullptr; ca.C1 = a.C; ca.C2 = b ? b->C : 0;
@@ -1766,6 +1767,7 @@ class Engine {
     split_stagger_mode_ = e ? atoi(e) : 0;
     coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);
     poison_ = flag("SGMSE_POISON", false);
+    conv_xcd_map_ = flag("SGMSE_CONV_XCD_MAP", false);      // XCD-aware tile order of the convolution kernels (ConvArgs::xcd_map): built, bit-identical, not yet measured
     debug_sync_ = flag("SGMSE_DEBUG_SYNC", false);          // synchronise after every launch of the forward and print its label (stderr)
     entry_mfma_ = flag("SGMSE_ENTRY_MFMA", true);           // entry convolution on the fp32 MFMA kernel (input channels padded to 8)
     fold_shortcut_ = flag("SGMSE_FOLD_SHORTCUT", true);
@@ -1828,7 +1830,7 @@ class Engine {
   int split_stagger_mode_ = 0;
   bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true, entry_mfma_ = true;
   ConvW entry8_{}; int entry8_idx_ = -1;
-  bool poison_ = false, debug_sync_ = false;
+  bool poison_ = false, debug_sync_ = false, conv_xcd_map_ = false;
   long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8, chunk_min_tiles_ = 2;
   int chunk_min_width_ = 32;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;

@@ -121,7 +121,15 @@ struct ConvArgs {
   // chunk workgroup of a tile that arrives LAST sums the tile's partial sums in chunk order and runs the epilogue itself -- what
   // conv_splitk_reduce_kernel would do behind this launch, bit for bit.  null: the reduce kernel follows.
   unsigned* splitk_ctr;
+  // XCD-aware tile order (0: off, the default until measured).  Workgroups are dealt round-robin over the 8 XCDs by their linear
+  // id and every XCD has its own L2: with the plain map a tile's vertical neighbour sits on the same XCD only when the tile row is a
+  // multiple of 8 tiles long (T = 512: 16 tiles) -- other lengths fetch every halo row again (profiles/r03_length_sweep.txt: 3-4 %
+  // per frame at T = 384 / 448 / 576 / 640).  With the map on, XCD k takes the k-th contiguous eighth of the launch's tiles, in order.
+  // A pure permutation of which workgroup computes which tile: results cannot change.
+  int xcd_map;
 };
+// dispatch id -> tile id under ConvArgs::xcd_map (nt tiles along gridDim.x; needs nt % 8 == 0, which 8-row tiles of a 256-bin image give)
+__device__ __forceinline__ int conv_xcd_tile(int t, int nt, int on) { return (on && (nt & 7) == 0) ? (t & 7) * (nt >> 3) + (t >> 3) : t; }
 
 constexpr int kAmaxSpread = 64;
 
@@ -655,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
   const int Cin = p.C1 + p.C2;
   const int tiles_xg = (p.W + 31) >> 5;       // grid layout (ragged launches: of the widest utterance)
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
-  int bid = blockIdx.x;
+  int bid = conv_xcd_tile((int)blockIdx.x, (int)gridDim.x, p.xcd_map);
   const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
@@ -945,7 +953,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
   const int tid = threadIdx.x;
   const int tiles_xg = (p.W + 31) >> 5;
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
-  int bid = blockIdx.x;
+  int bid = conv_xcd_tile((int)blockIdx.x, (int)gridDim.x, p.xcd_map);
   const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;

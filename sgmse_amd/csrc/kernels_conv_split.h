@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   const int Cin = p.C1 + p.C2;
   const int tiles_xg = (p.W + 31) >> 5;       // grid layout (ragged launches: of the widest utterance)
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
-  int bid = blockIdx.x;
+  int bid = conv_xcd_tile((int)blockIdx.x, (int)gridDim.x, p.xcd_map);
   const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
   const int Cin = p.C1 + p.C2;
   const int tiles_xg = (p.W + 31) >> 5;       // grid layout (ragged launches: of the widest utterance)
   const int tiles_y = (p.H + 7) >> 3;
-  int bid = blockIdx.x;
+  int bid = conv_xcd_tile((int)blockIdx.x, (int)gridDim.x, p.xcd_map);
   const int tx = bid % tiles_xg; bid /= tiles_xg;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;

@@ -244,6 +244,30 @@ def check_split_workgroup_shapes_bitwise(dev, name="fwd_nf128"):
     assert rel_l2(outs[0], torch.from_numpy(z["out"])) < NET_TOL
 
 
+def check_xcd_map_bitwise(dev, name="fwd_nf32", batch=None):
+    """SGMSE_CONV_XCD_MAP=1 only permutes which workgroup computes which tile (XCD k takes the k-th contiguous eighth of a launch's
+    tiles): the network's output must not change by a bit."""
+    cfg = NET_CASES[name]
+    z = load(name)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    if batch is not None:
+        x, t = x[:batch], t[:batch]
+    old = os.environ.get("SGMSE_CONV_XCD_MAP")
+    outs = []
+    try:
+        for m in ("0", "1"):
+            os.environ["SGMSE_CONV_XCD_MAP"] = m
+            net, _ = make_backbone(cfg, dev)
+            outs.append(net(x.to(dev), t.to(dev)).cpu())
+    finally:
+        if old is None:
+            os.environ.pop("SGMSE_CONV_XCD_MAP", None)
+        else:
+            os.environ["SGMSE_CONV_XCD_MAP"] = old
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[0], torch.from_numpy(z["out"])[:len(x)]) < NET_TOL
+
+
 def check_gn_tail_bitwise(dev, name="fwd_nf128", batch=None):
     """Work finished by the LAST workgroup to arrive instead of by a second launch: GroupNorm coefficients in the tail of the
     producing convolution (last workgroup of each utterance, ConvArgs::fin) vs gn_finalize_kernel launches, and the split-K

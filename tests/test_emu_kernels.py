@@ -141,6 +141,10 @@ def test_conv_tile_shape_never_changes_a_bit(emu):
     P.check_tile_independence(emu, "fwd_nf32", batch=1)
 
 
+def test_xcd_aware_tile_order_never_changes_a_bit(emu):
+    P.check_xcd_map_bitwise(emu, "fwd_nf32", batch=1)
+
+
 def test_groupnorm_coefficients_in_the_convolution_tail_never_change_a_bit(emu):
     """last-workgroup finalize (workgroups run on a thread pool here: the arrival order varies) vs gn_finalize_kernel launches"""
     P.check_gn_tail_bitwise(emu, "fwd_nf32", batch=1)

@@ -464,6 +464,12 @@ def test_split_k_of_the_coarse_levels_never_changes_a_bit(hip):
 
 
 @pytest.mark.parametrize("name", ["fwd_nf32", "fwd_nf128"])
+def test_xcd_aware_tile_order_never_changes_a_bit(hip, name):
+    """SGMSE_CONV_XCD_MAP=1 (off by default, to be measured): a permutation of the tile -> workgroup assignment of the convolutions"""
+    P.check_xcd_map_bitwise(hip, name)
+
+
+@pytest.mark.parametrize("name", ["fwd_nf32", "fwd_nf128"])
 def test_groupnorm_coefficients_in_the_convolution_tail_never_change_a_bit(hip, name):
     """GroupNorm coefficients finished by the last workgroup of each utterance in the producing launch (device-scope release /
     acquire around an arrival counter) vs gn_finalize_kernel launches: bit-identical network output, batch of fixtures."""
