@@ -284,8 +284,13 @@ def check_gn_tail_bitwise(dev, name="fwd_nf128", batch=None):
     outs, jobs = [], []
     try:
         # (tails, size limit, fused split-K, arrival: 0 release / acquire fences, 1 device-coherent accesses without cache maintenance)
-        for tail, pairs, fused, mode in (("0", None, "0", "0"), ("1", None, "1", "0"), ("1", "1000000000", "1", "0"), ("0", None, "1", "0"),
-                                         ("1", None, "0", "0"), ("1", None, "0", "1"), ("1", "1000000000", "1", "1")):
+        cases = [("0", None, "0", "0"), ("1", None, "1", "0"), ("1", "1000000000", "1", "0"), ("0", None, "1", "0"), ("1", None, "0", "0")]
+        # the experimental arrival (device-coherent accesses, no cache maintenance) rests on hardware behaviour no specification
+        # available here states: it passed on the GPU in both runs of the final visit (profiles/r03_pytest_gpu*.log), and is kept out
+        # of the default suite so that it cannot make the suite flaky; SGMSE_TEST_TAIL_MODE1=1 adds it (always on the emulator)
+        if dev == "cpu" or os.environ.get("SGMSE_TEST_TAIL_MODE1") == "1":
+            cases += [("1", None, "0", "1"), ("1", "1000000000", "1", "1")]
+        for tail, pairs, fused, mode in cases:
             os.environ["SGMSE_GN_TAIL"] = tail
             os.environ["SGMSE_SPLITK_FUSED"] = fused
             os.environ["SGMSE_GN_TAIL_MODE"] = mode
@@ -303,7 +308,8 @@ def check_gn_tail_bitwise(dev, name="fwd_nf128", batch=None):
             else:
                 os.environ[k] = v
     print(f"{name} on {dev}: GroupNorm jobs in convolution tails: off {jobs[0]}, default limit {jobs[1]}, no limit {jobs[2]}")
-    assert jobs[0] == 0 and jobs[3] == 0 and jobs[1] > 0 and jobs[2] >= jobs[1] and jobs[4] == jobs[1] and jobs[5] == jobs[1] and jobs[6] == jobs[2], jobs
+    assert jobs[0] == 0 and jobs[3] == 0 and jobs[1] > 0 and jobs[2] >= jobs[1] and jobs[4] == jobs[1], jobs
+    assert len(jobs) == 5 or (jobs[5] == jobs[1] and jobs[6] == jobs[2]), jobs
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
     assert rel_l2(outs[0], torch.from_numpy(z["out"])[:len(x)]) < NET_TOL
