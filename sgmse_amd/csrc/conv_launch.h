@@ -28,10 +28,16 @@ inline int conv_variant() {
   return v;
 }
 
+// tiles along gridDim.x: B x tile rows x tile columns of the (widest) utterance, or tile rows x the tile columns that exist (ConvArgs::rag_cols)
+inline int conv_grid_tiles(const ConvArgs& a, int rows) {
+  const int ty = (a.H + rows - 1) / rows;
+  return a.rag_cols ? ty * a.rag_ncols : a.B * ty * ((a.W + 31) / 32);
+}
+
 template <int KS, int WC, int FC, int FP>
 inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant, int ksplit = 1) {
   using T = ConvTile<KS, WC, FC, FP>;
-  const int tiles = a.B * ((a.H + T::ROWS - 1) / T::ROWS) * ((a.W + 31) / 32);
+  const int tiles = conv_grid_tiles(a, T::ROWS);
   dim3 grid(tiles, (a.Cout + T::CO_T - 1) / T::CO_T, ksplit);
   if (variant < 0) variant = conv_variant();
   const bool vec = (a.rag_w ? a.rag_vec_ok != 0 : a.W % 4 == 0) && !(variant & 2) && (reinterpret_cast<uintptr_t>(a.src1) % 16 == 0) &&
@@ -60,7 +66,7 @@ inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt:
     const int kc = (v & 16) ? 64 : 32;
     const int Cin = a.C1 + a.C2;
     if (Cin % kc == 0 && (a.src2 == nullptr || a.C1 % kc == 0)) {
-      const int tiles = a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32);
+      const int tiles = conv_grid_tiles(a, 4);
       dim3 grid(tiles, a.Cout / 128, 1);
       if (kc == 64) DRT_LAUNCH((conv1x1_stream_kernel<1, 64>), grid, dim3(256), st, a);
       else DRT_LAUNCH((conv1x1_stream_kernel<1, 32>), grid, dim3(256), st, a);
@@ -128,16 +134,16 @@ inline void launch_conv3x3_split_t(const ConvArgs& a, dim3 grid, drt::stream_t s
 // (two rows per wave; its layers emit no statistics in the network)
 inline int conv_split_stats_rows(int ks, int Cout) { return (ks == 3 && Cout <= 32) ? 1 : 4; }
 inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t st, bool rows4 = false, int abl = 0, int ksplit = 1) {
-  const int tiles = a.B * ((a.H + 7) / 8) * ((a.W + 31) / 32);
+  const int tiles = conv_grid_tiles(a, 8);
   if (ks == 3 && a.Cout > 32 && rows4 && a.kchunk_stages > 0 && mode == 2) {     // chunked accumulation / split-K (coarse levels)
-    const dim3 grid(a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32), a.Cout / 128, ksplit);
+    const dim3 grid(conv_grid_tiles(a, 4), a.Cout / 128, ksplit);
     if (a.in_scale && a.in_act) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2, 1, 0, 0, 0, 1>), grid, dim3(256), st, a);
     else DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2, 0, 0, 0, 0, 1>), grid, dim3(256), st, a);
     if (ksplit > 1 && !a.splitk_ctr) DRT_LAUNCH((conv_splitk_reduce_kernel<3, 4, 1, 4, true>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
     return;
   }
   if (ks == 3 && a.Cout > 32 && rows4) {
-    const dim3 grid(a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32), a.Cout / 128, 1);
+    const dim3 grid(conv_grid_tiles(a, 4), a.Cout / 128, 1);
     if (mode == 2) launch_conv3x3_split_t<SplitH2, 2>(a, grid, st); else launch_conv3x3_split_t<SplitB3, 2>(a, grid, st);
     return;
   }

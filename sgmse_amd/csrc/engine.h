@@ -1107,15 +1107,16 @@ class Engine {
     for (int t : rag_T_) { SG_REQUIRE(t >= down && t % down == 0, "ragged batch: frame counts must be multiples of 2^(levels-1)"); tmax = std::max(tmax, t); }
     SG_REQUIRE(tmax == T, "ragged batch: T must be the largest frame count");
     for (void* q : rag_owned_) dev_free_owned(q);
-    rag_owned_.clear(); rag_w_dev_.clear(); rag_off_dev_.clear(); rag_soff_dev_.clear(); rag_pix_.clear();
+    rag_owned_.clear(); rag_w_dev_.clear(); rag_off_dev_.clear(); rag_soff_dev_.clear(); rag_pix_.clear(); rag_cols_dev_.clear(); rag_ncols_.clear();
     for (int l = 0; l < L; ++l) {
       const int H = F >> l;
-      std::vector<int> w(B);
+      std::vector<int> w(B), cols(B + 1, 0);
       std::vector<long long> off(B + 1, 0), soff(B + 1, 0);
       for (int b = 0; b < B; ++b) {
         w[b] = rag_T_[b] >> l;
         off[b + 1] = off[b] + (long long)H * w[b];
         soff[b + 1] = soff[b] + (long long)H * ((w[b] + 31) / 32);
+        cols[b + 1] = cols[b] + (w[b] + 31) / 32;             // tile columns that exist (ConvArgs::rag_cols)
       }
       int* wd = static_cast<int*>(dev_alloc((size_t)B * 4));
       long long* od = static_cast<long long*>(dev_alloc((size_t)(B + 1) * 8));
@@ -1123,7 +1124,10 @@ class Engine {
       SG_CHECK(drt::memcpy_h2d(wd, w.data(), (size_t)B * 4, stream_));
       SG_CHECK(drt::memcpy_h2d(od, off.data(), (size_t)(B + 1) * 8, stream_));
       SG_CHECK(drt::memcpy_h2d(sd, soff.data(), (size_t)(B + 1) * 8, stream_));
+      int* cd = static_cast<int*>(dev_alloc((size_t)(B + 1) * 4));
+      SG_CHECK(drt::memcpy_h2d(cd, cols.data(), (size_t)(B + 1) * 4, stream_));
       SG_CHECK(drt::stream_sync(stream_));
+      rag_owned_.push_back(cd); rag_cols_dev_.push_back(cd); rag_ncols_.push_back(cols[B]);
       rag_owned_.push_back(wd); rag_owned_.push_back(od); rag_owned_.push_back(sd);
       rag_w_dev_.push_back(wd); rag_off_dev_.push_back(od); rag_soff_dev_.push_back(sd);
       rag_pix_.push_back((size_t)off[B]);
@@ -1132,6 +1136,7 @@ class Engine {
   }
   std::vector<int> rag_T_;
   std::vector<int*> rag_w_dev_; std::vector<long long*> rag_off_dev_, rag_soff_dev_; std::vector<size_t> rag_pix_;
+  std::vector<int*> rag_cols_dev_; std::vector<int> rag_ncols_;
   std::vector<void*> rag_owned_;
   bool rag_built_ = false;
   int cur_F_ = 0;
@@ -1344,6 +1349,7 @@ class Engine {
       const Rag rg = rag_of(a.H);
       ca.rag_w = rg.w; ca.rag_off = rg.off; ca.rag_soff = rg.soff; ca.rag_slab = (long long)w.cout * (long long)pix_total(a.H, a.W);
       ca.rag_vec_ok = rag_all_mult4(a.H) ? 1 : 0;
+      if (rag_prefix_) { const int l = level_of(a.H); ca.rag_cols = rag_cols_dev_.at(l); ca.rag_ncols = rag_ncols_.at(l); }
     }
     tock();
     double fl = 2.0 * B_ * (double)w.cout * Cin * w.ks * w.ks * a.H * a.W;
@@ -1374,8 +1380,8 @@ class Engine {
       launch_conv_split(ca, w.ks, w.split_mode, stream_, rows4, 0, ksplit);
       if (coarse_split && partial) arena_.release(partial);
       if (noting())
-        snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "",
-                 sc ? " +shortcut" : "");
+        snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "",
+                 sc ? " +shortcut" : "", ca.rag_cols ? " existing-tiles" : "");
       tick(w.ks == 3 ? (w.cout >= 128 ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else if (use_mfma) {
       ConvPlan pl{co_t, rows_, true};
@@ -1384,8 +1390,8 @@ class Engine {
       launch_conv_mfma(ca, w.ks, pl, stream_, -1, ksplit);
       if (partial) arena_.release(partial);
       if (noting())
-        snprintf(prof_note_, sizeof prof_note_, "conv%dx%d %d->%d @%dx%dx%d tile %dco x %drows%s%s%s", w.ks, w.ks, Cin, w.cout, B_, a.H, a.W,
-                 co_t, rows_, res ? " +res" : "", xf.scale ? " +gn" : "", ksplit > 1 ? " split-K" : "");
+        snprintf(prof_note_, sizeof prof_note_, "conv%dx%d %d->%d @%dx%dx%d tile %dco x %drows%s%s%s%s", w.ks, w.ks, Cin, w.cout, B_, a.H, a.W,
+                 co_t, rows_, res ? " +res" : "", xf.scale ? " +gn" : "", ksplit > 1 ? " split-K" : "", ca.rag_cols ? " existing-tiles" : "");
       // class "wide" = the dominant kernel family only: the split kernels, or (SGMSE_CONV_SPLIT=0) the fp32 128 x 256 tile
       tick(w.ks == 3 ? ((split_mode_ == 0 && co_t == 128 && pl.rows == 8) ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else {
@@ -1767,6 +1773,7 @@ class Engine {
     split_stagger_mode_ = e ? atoi(e) : 0;
     coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);
     poison_ = flag("SGMSE_POISON", false);
+    rag_prefix_ = flag("SGMSE_RAGGED_PREFIX", false);       // ragged convolution launches over the tiles that exist (ConvArgs::rag_cols): built, bit-identical, not yet measured
     conv_xcd_map_ = flag("SGMSE_CONV_XCD_MAP", false);      // XCD-aware tile order of the convolution kernels (ConvArgs::xcd_map): built, bit-identical, not yet measured
     debug_sync_ = flag("SGMSE_DEBUG_SYNC", false);          // synchronise after every launch of the forward and print its label (stderr)
     entry_mfma_ = flag("SGMSE_ENTRY_MFMA", true);           // entry convolution on the fp32 MFMA kernel (input channels padded to 8)
@@ -1830,7 +1837,7 @@ class Engine {
   int split_stagger_mode_ = 0;
   bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true, entry_mfma_ = true;
   ConvW entry8_{}; int entry8_idx_ = -1;
-  bool poison_ = false, debug_sync_ = false, conv_xcd_map_ = false;
+  bool poison_ = false, debug_sync_ = false, conv_xcd_map_ = false, rag_prefix_ = false;
   long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8, chunk_min_tiles_ = 2;
   int chunk_min_width_ = 32;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;

@@ -127,9 +127,29 @@ struct ConvArgs {
   // per frame at T = 384 / 448 / 576 / 640).  With the map on, XCD k takes the k-th contiguous eighth of the launch's tiles, in order.
   // A pure permutation of which workgroup computes which tile: results cannot change.
   int xcd_map;
+  // Ragged launch laid out over the tiles that EXIST (null: over the widest utterance's tile columns, tiles beyond an utterance's
+  // width exit).  rag_cols[b] = sum over the utterances before b of ceil(W_b' / 32) (B + 1 entries), rag_ncols = rag_cols[B]:
+  // gridDim.x = tiles_y * rag_ncols, utterance b owns the ids [tiles_y * rag_cols[b], tiles_y * rag_cols[b + 1]), row-major inside.
+  // An exiting workgroup still has to be dispatched with the kernel's LDS and registers; a batch of 2 ... 6 s utterances launches
+  // 24 576 tile columns for 16 896 used, and its convolutions take 1.14x per frame (profiles/r03_ragged_per_launch_dump.txt).
+  const int* rag_cols; int rag_ncols;
 };
 // dispatch id -> tile id under ConvArgs::xcd_map (nt tiles along gridDim.x; needs nt % 8 == 0, which 8-row tiles of a 256-bin image give)
 __device__ __forceinline__ int conv_xcd_tile(int t, int nt, int on) { return (on && (nt & 7) == 0) ? (t & 7) * (nt >> 3) + (t >> 3) : t; }
+// dispatch id t of nt -> utterance b, tile row ty, tile column tx (every convolution kernel's first step)
+__device__ __forceinline__ void conv_tile_of(const ConvArgs& p, int t, int nt, int tiles_xg, int tiles_y, int& b, int& ty, int& tx) {
+  int bid = conv_xcd_tile(t, nt, p.xcd_map);
+  if (p.rag_cols) {                        // (uniform: a handful of dependent scalar loads)
+    int lo = 0, hi = p.B;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.rag_cols[mid] * tiles_y <= bid) lo = mid; else hi = mid; }
+    const int c0 = p.rag_cols[lo], nx = p.rag_cols[lo + 1] - c0, r = bid - c0 * tiles_y;
+    b = lo; ty = r / nx; tx = r - ty * nx;
+  } else {
+    tx = bid % tiles_xg; bid /= tiles_xg;
+    ty = bid % tiles_y;
+    b = bid / tiles_y;
+  }
+}
 
 constexpr int kAmaxSpread = 64;
 
@@ -663,10 +683,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
   const int Cin = p.C1 + p.C2;
   const int tiles_xg = (p.W + 31) >> 5;       // grid layout (ragged launches: of the widest utterance)
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
-  int bid = conv_xcd_tile((int)blockIdx.x, (int)gridDim.x, p.xcd_map);
-  const int tx = bid % tiles_xg; bid /= tiles_xg;
-  const int ty = bid % tiles_y;
-  const int b = bid / tiles_y;
+  int b, ty, tx;
+  conv_tile_of(p, (int)blockIdx.x, (int)gridDim.x, tiles_xg, tiles_y, b, ty, tx);
   if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
   const int tiles_x = (p.W + 31) >> 5;
   const int x0 = tx * 32, y0 = ty * ROWS;
@@ -953,10 +971,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
   const int tid = threadIdx.x;
   const int tiles_xg = (p.W + 31) >> 5;
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
-  int bid = conv_xcd_tile((int)blockIdx.x, (int)gridDim.x, p.xcd_map);
-  const int tx = bid % tiles_xg; bid /= tiles_xg;
-  const int ty = bid % tiles_y;
-  const int b = bid / tiles_y;
+  int b, ty, tx;
+  conv_tile_of(p, (int)blockIdx.x, (int)gridDim.x, tiles_xg, tiles_y, b, ty, tx);
   if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;

@@ -38,10 +38,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs p) {
   const int Cin = p.C1 + p.C2;
   const int tiles_xg = (p.W + 31) >> 5;       // grid layout (ragged launches: of the widest utterance)
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
-  int bid = conv_xcd_tile((int)blockIdx.x, (int)gridDim.x, p.xcd_map);
-  const int tx = bid % tiles_xg; bid /= tiles_xg;
-  const int ty = bid % tiles_y;
-  const int b = bid / tiles_y;
+  int b, ty, tx;
+  conv_tile_of(p, (int)blockIdx.x, (int)gridDim.x, tiles_xg, tiles_y, b, ty, tx);
   if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
   const int tiles_x = (p.W + 31) >> 5;
   const int x0 = tx * 32, y0 = ty * ROWS;

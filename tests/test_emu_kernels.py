@@ -253,6 +253,15 @@ def test_ragged_batch_gives_every_utterance_its_single_run_bits(emu):
     P.check_ragged_batch(emu, "fwd_nf32", frames=(128, 64), quick=True)
 
 
+def test_ragged_launches_over_the_tiles_that_exist_give_the_same_bits(emu, monkeypatch):
+    """SGMSE_RAGGED_PREFIX=1 (+ the XCD-aware tile order): the convolutions of a ragged batch are launched over the tile columns that
+    exist instead of the widest utterance's; every utterance must still get the bits of its single run (three utterances, widths
+    that leave partial tiles at the coarse levels)."""
+    monkeypatch.setenv("SGMSE_RAGGED_PREFIX", "1")
+    monkeypatch.setenv("SGMSE_CONV_XCD_MAP", "1")
+    P.check_ragged_batch(emu, "fwd_nf32", frames=(128, 64, 192), quick=True)
+
+
 @pytest.mark.skipif(not os.environ.get("SGMSE_SLOW"), reason="full-width network on the emulator: minutes (SGMSE_SLOW=1)")
 def test_ragged_batch_full_width(emu):
     P.check_ragged_batch(emu, "fwd_nf128", frames=(128, 64), sampler=False)

@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP library (libsgmse_hip.so, gfx950) through the Python host layer / C ABI against the
 oracle and the reference-made fixtures.  Run on the GPU box with `pytest -m gpu`."""
 import math
+import os
 
 import pytest
 import torch
@@ -488,6 +489,14 @@ def test_sampler_does_not_depend_on_what_device_memory_held(hip, monkeypatch):
 
 def test_ragged_batch_gives_every_utterance_its_single_run_bits(hip):
     """Full width, frame counts from 64 to 512 in one batch: forward, PC, corrector-free PC and PF-ODE samplers (captured graph)."""
+    P.check_ragged_batch(hip, "fwd_nf128", frames=(512, 64, 192, 320, 128))
+
+
+@pytest.mark.skipif(not os.environ.get("SGMSE_TEST_EXPERIMENTAL"), reason="built after the round's GPU time was spent: run with SGMSE_TEST_EXPERIMENTAL=1")
+def test_ragged_launches_over_the_tiles_that_exist_give_the_same_bits(hip, monkeypatch):
+    """SGMSE_RAGGED_PREFIX=1 + SGMSE_CONV_XCD_MAP=1 at full width (see the emulator test of the same name)"""
+    monkeypatch.setenv("SGMSE_RAGGED_PREFIX", "1")
+    monkeypatch.setenv("SGMSE_CONV_XCD_MAP", "1")
     P.check_ragged_batch(hip, "fwd_nf128", frames=(512, 64, 192, 320, 128))
 
 
