@@ -1298,7 +1298,12 @@ class Engine {
     // (not in ragged launches: the full-width five-utterance case of test_ragged_batch_gives_every_utterance_its_single_run_bits
     // faulted on the GPU with the tails on -- at the 4 x 8 level, utterance widths 8 / 1 / 3 / 5 / 2 -- while the same composition
     // runs clean on the emulator under AddressSanitizer; unresolved, and the mechanism is off by default anyway)
-    if (hints && gn_tail_ && !ragged() && o.st && o.nsub >= 1 && use_mfma && !(use_split && w.ks == 1)) {   // (conv1x1_split_kernel has no tail)
+#ifdef SGMSE_TAIL_IN_RAGGED          // (debugging the fault described above: tails in ragged launches too)
+    const bool tail_ok = true;
+#else
+    const bool tail_ok = !ragged();
+#endif
+    if (hints && gn_tail_ && tail_ok && o.st && o.nsub >= 1 && use_mfma && !(use_split && w.ks == 1)) {   // (conv1x1_split_kernel has no tail)
       for (int k = 0; k < hints->n; ++k) {
         const GnHint& hn = hints->h[k];
         const Tensor* hb = hn.b;
