@@ -331,7 +331,6 @@ def measure(env, a, workload, batch, steps, warmup, sampler=None, N=None, snr=No
     if power and power.summary():
         out["power"] = power.summary()
     out["graph_captures_rank0"] = ctx.graph_captures()   # 1: the seed changes per step, the captured step does not
-    out["gn_tail_jobs_per_eval"] = ctx.gn_tail_jobs()    # GroupNorm coefficient computations finished inside the producing launch
     if world > 1:
         out["weight_broadcast_ms"] = bcast_ms
         out["per_rank_utt_per_s"] = [batch * steps / t for t in per_rank]
@@ -388,7 +387,7 @@ def main():
                 o, m = measure(env, a, wname, batch, steps, 1)
                 del m
                 others[key] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "rtf", "steps", "warmup", "config", "roofline",
-                                                 "kernel_classes_one_eval", "graph_captures_rank0", "gn_tail_jobs_per_eval") if k in o}
+                                                 "kernel_classes_one_eval", "graph_captures_rank0") if k in o}
             except Exception as e:      # noqa: BLE001 -- the headline stands on its own
                 others[key] = {"error": f"{type(e).__name__}: {e}"}
         out["other_workloads"] = others

@@ -183,11 +183,6 @@ int sgmse_graph_captures(sgmse_ctx* ctx, int* out);
 /* how many times a captured step was brought up to date IN PLACE (hipGraphExecUpdate: same launch sequence, other arguments --
  * a new ragged batch composition, a new batch size of the same kernel sequence) instead of being instantiated anew */
 int sgmse_graph_updates(sgmse_ctx* ctx, int* out);
-/* how many GroupNorm coefficient computations of the forward planned for the current shape run in the tail of the producing
- * convolution launch (last workgroup of each utterance) instead of as a gn_finalize launch of their own; 0 before the first
- * forward / sampler call of a shape.  Replaces nothing in the reference (nn.GroupNorm, layerspp.py:219,231, computes its
- * statistics inside the op); tests and bench.py report it. */
-int sgmse_gn_tail_jobs(sgmse_ctx* ctx, int* out);
 
 #ifdef __cplusplus
 }

@@ -71,7 +71,6 @@ _SIGS = {
     "sgmse_arena_bytes": (_I, [_P, C.POINTER(_LL)]),
     "sgmse_graph_captures": (_I, [_P, C.POINTER(_I)]),
     "sgmse_graph_updates": (_I, [_P, C.POINTER(_I)]),
-    "sgmse_gn_tail_jobs": (_I, [_P, C.POINTER(_I)]),
     "sgmse_set_noise_streams": (_I, [_P, C.POINTER(C.c_ulonglong), _I]),
     "sgmse_set_frames": (_I, [_P, C.POINTER(_I), _I]),
 }
@@ -465,12 +464,6 @@ class Context:
         """Number of times a captured step was updated in place (hipGraphExecUpdate) instead of being instantiated anew."""
         out = _I(0)
         self.check(self.lib.sgmse_graph_updates(self.h, C.byref(out)))
-        return out.value
-
-    def gn_tail_jobs(self) -> int:
-        """GroupNorm coefficient computations of the planned forward that run in the tail of the producing convolution launch."""
-        out = _I(0)
-        self.check(self.lib.sgmse_gn_tail_jobs(self.h, C.byref(out)))
         return out.value
 
     def arena_bytes(self) -> int:

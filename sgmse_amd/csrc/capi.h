@@ -220,9 +220,4 @@ int sgmse_graph_updates(sgmse_ctx* ctx, int* out) {
   return sg_guard(ctx, [&](sgmse::Engine& e) { *out = e.graph_updates(); });
 }
 
-int sgmse_gn_tail_jobs(sgmse_ctx* ctx, int* out) {
-  SG_ARG(ctx, out != nullptr, "out is null");
-  return sg_guard(ctx, [&](sgmse::Engine& e) { *out = e.gn_tail_jobs(); });
-}
-
 }  // extern "C"

@@ -4,12 +4,10 @@
 #include "kernels_conv_pipe.h"
 #include "kernels_conv1x1.h"
 #include "kernels_conv_split.h"
+#include "kernels_conv_wino.h"
 
 #ifndef SGMSE_CONV_SPLIT_DEFAULT
 #define SGMSE_CONV_SPLIT_DEFAULT 2     // 0: fp32 MFMA everywhere, 1: bf16x3 on the wide levels, 2: fp16x2 on the wide levels
-#endif
-#ifndef SGMSE_SPLIT_STAGGER_DEFAULT
-#define SGMSE_SPLIT_STAGGER_DEFAULT 0  // cycles per K-stage by which the first residency round of the split 3x3 kernel is de-phased (0: off)
 #endif
 #ifndef SGMSE_CONV_PIPE_DEFAULT
 #define SGMSE_CONV_PIPE_DEFAULT 1
@@ -52,12 +50,11 @@ inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant,
   else if (pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 0>), grid, dim3(256), st, a);
   else DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 0>), grid, dim3(256), st, a);
   if constexpr (FC * FP <= 2) {
-    if (ksplit > 1 && !a.splitk_ctr) DRT_LAUNCH((conv_splitk_reduce_kernel<KS, WC, FC, FP>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
+    if (ksplit > 1) DRT_LAUNCH((conv_splitk_reduce_kernel<KS, WC, FC, FP>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
   }
 }
 
-// ksplit > 1 (small tiles only, ConvArgs::kchunk_stages chunks): split-K over gridDim.z + the reduce/epilogue kernel (or, with
-// ConvArgs::splitk_ctr, the reduce and epilogue by the last chunk workgroup of each tile: no second launch)
+// ksplit > 1 (small tiles only, ConvArgs::kchunk_stages chunks): split-K over gridDim.z + the reduce/epilogue kernel
 inline void launch_conv_mfma(const ConvArgs& a, int ks, const ConvPlan& pl, drt::stream_t st, int variant = -1, int ksplit = 1) {
   const int v = variant < 0 ? conv_variant() : variant;
   if (ks == 1 && pl.co_t == 128 && (v & 8)) {
@@ -101,32 +98,15 @@ inline bool conv_thin_split_eligible(int ks, int C1, int C2, int Cout) {
 // mode 1: bf16x3, mode 2: fp16x2 (a.acc_scale must point at the factor stored behind the packed weights)
 // rows4: the 4-row workgroup shape of the full 3x3 kernel (same results; for launches that cannot fill the chip)
 // abl: measurement-only ablation instantiations of the dominant shape (fp16x2, 8 rows, SiLU producer), see the kernel
-// SGMSE_SPLIT_BLK: register blocking of the split 3x3 kernel's waves (kernels_conv_split.h, BLK): 0 = 1 x 8, 1 = 2 x 4 fragments
-#ifndef SGMSE_SPLIT_BLK_DEFAULT
-#define SGMSE_SPLIT_BLK_DEFAULT 0
-#endif
-inline int split_blk() {
-  static int v = [] { const char* e = getenv("SGMSE_SPLIT_BLK"); return e ? atoi(e) : SGMSE_SPLIT_BLK_DEFAULT; }();
-  return v;
-}
 template <class S, int SHAPE>
 inline void launch_conv3x3_split_t(const ConvArgs& a, dim3 grid, drt::stream_t st) {
   const bool act = a.in_scale && a.in_act;
   if constexpr (SHAPE != 1 && S::SCALED) {
     if (a.sc_w) {                                  // folded residual shortcut (fp16x2, SiLU producer, full-block shapes)
-      DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1, 0, 0, 1>), grid, dim3(256), st, a);
+      DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1, 0, 1>), grid, dim3(256), st, a);
       return;
     }
   }
-#ifdef SGMSE_ABLATION_FULL
-  if constexpr (SHAPE == 0) {
-    if (split_blk() == 1) {            // 2 x 4 register blocking: measured equal to 1 x 8 (profiles/r02: gpu_r02_blk.sh), not built by default
-      if (act) DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1, 0, 1>), grid, dim3(256), st, a);
-      else DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 0, 0, 1>), grid, dim3(256), st, a);
-      return;
-    }
-  }
-#endif
   if (act) DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 1>), grid, dim3(256), st, a);
   else DRT_LAUNCH((conv3x3_split_kernel<S, SHAPE, 0>), grid, dim3(256), st, a);
 }
@@ -137,9 +117,9 @@ inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t
   const int tiles = conv_grid_tiles(a, 8);
   if (ks == 3 && a.Cout > 32 && rows4 && a.kchunk_stages > 0 && mode == 2) {     // chunked accumulation / split-K (coarse levels)
     const dim3 grid(conv_grid_tiles(a, 4), a.Cout / 128, ksplit);
-    if (a.in_scale && a.in_act) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2, 1, 0, 0, 0, 1>), grid, dim3(256), st, a);
-    else DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2, 0, 0, 0, 0, 1>), grid, dim3(256), st, a);
-    if (ksplit > 1 && !a.splitk_ctr) DRT_LAUNCH((conv_splitk_reduce_kernel<3, 4, 1, 4, true>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
+    if (a.in_scale && a.in_act) DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2, 1, 0, 0, 1>), grid, dim3(256), st, a);
+    else DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 2, 0, 0, 0, 1>), grid, dim3(256), st, a);
+    if (ksplit > 1) DRT_LAUNCH((conv_splitk_reduce_kernel<3, 4, 1, 4, true>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
     return;
   }
   if (ks == 3 && a.Cout > 32 && rows4) {
@@ -159,16 +139,37 @@ inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t
   const dim3 grid(tiles, a.Cout / 128, 1);
   if (abl && mode == 2) {
 #define SGMSE_ABL_CASE(V) if (abl == V) { DRT_LAUNCH((conv3x3_split_kernel<SplitH2, 0, 1, V>), grid, dim3(256), st, a); return; }
-    // the variants tools/power_probe.py and the phase trace need are always built; the full series behind
-    // profiles/r02_split_*.txt with `make ABLATION=1` (each instantiation of this kernel costs ~6 s of build time)
-    SGMSE_ABL_CASE(8) SGMSE_ABL_CASE(59) SGMSE_ABL_CASE(64)
+    // the measurement series behind profiles/r02_split_*.txt and tools/power_probe.py's ablation cases: `make ABLATION=1` only
+    // (each instantiation of this kernel costs ~6 s of build time; the product library carries none of them)
 #ifdef SGMSE_ABLATION_FULL
+    SGMSE_ABL_CASE(8) SGMSE_ABL_CASE(59) SGMSE_ABL_CASE(64)
     SGMSE_ABL_CASE(3) SGMSE_ABL_CASE(4) SGMSE_ABL_CASE(24) SGMSE_ABL_CASE(56)
     SGMSE_ABL_CASE(1) SGMSE_ABL_CASE(2) SGMSE_ABL_CASE(67) SGMSE_ABL_CASE(72) SGMSE_ABL_CASE(128) SGMSE_ABL_CASE(256) SGMSE_ABL_CASE(512)
 #endif
 #undef SGMSE_ABL_CASE
   }
   if (mode == 2) launch_conv3x3_split_t<SplitH2, 0>(a, grid, st); else launch_conv3x3_split_t<SplitB3, 0>(a, grid, st);
+}
+
+// Winograd F(2,3) x fp16x2 kernel of the wide levels (kernels_conv_wino.h); a.w = fragments packed by pack_weights_wino_kernel,
+// a.co_scale = the per-channel factors behind them.  rows4: the 4-row shape (same bits) for launches that cannot fill the chip.
+inline bool conv_wino_eligible(int C1, int C2, int Cout, int W) {
+  return Cout % 128 == 0 && (C1 + C2) % 16 == 0 && (C2 == 0 || C1 % 16 == 0) && (C1 + C2) <= 512 && W % 2 == 0;
+}
+inline void launch_conv_wino(const ConvArgs& a, drt::stream_t st, bool rows4, bool trace = false) {
+  const bool act = a.in_scale && a.in_act;
+  if (trace) { DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0, 1>), dim3(conv_grid_tiles(a, 8), a.Cout / 128, 1), dim3(512), st, a); return; }
+  if (rows4) {
+    const dim3 grid(conv_grid_tiles(a, 4), a.Cout / 128, 1);
+    if (a.sc_w) DRT_LAUNCH((conv3x3_wino_kernel<4, 1, 1>), grid, dim3(512), st, a);
+    else if (act) DRT_LAUNCH((conv3x3_wino_kernel<4, 1, 0>), grid, dim3(512), st, a);
+    else DRT_LAUNCH((conv3x3_wino_kernel<4, 0, 0>), grid, dim3(512), st, a);
+  } else {
+    const dim3 grid(conv_grid_tiles(a, 8), a.Cout / 128, 1);
+    if (a.sc_w) DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 1>), grid, dim3(512), st, a);
+    else if (act) DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0>), grid, dim3(512), st, a);
+    else DRT_LAUNCH((conv3x3_wino_kernel<8, 0, 0>), grid, dim3(512), st, a);
+  }
 }
 
 inline void launch_conv_direct(const ConvArgs& a, int ks, drt::stream_t st) {

@@ -241,14 +241,7 @@ class Arena {
 
 // st: [B][C][nsub][2] GroupNorm partial sums; amax: [B] upper bounds of |x| per utterance (null: unknown range)
 // srows: image rows per statistics sub-tile (1: the fp32 kernels, 4: the split kernels; ConvArgs::stats_rows)
-// pre: GroupNorm coefficients the producing launch's tail already computes for a consumer (Engine::conv, GnHint): the consumer,
-// identified by its gamma and by the second tensor of its virtual concat, takes them from here instead of launching gn_finalize_kernel
-struct GnPre { const float* gamma = nullptr; const float* other = nullptr; float* sc = nullptr; float* sh = nullptr; const float* bound = nullptr; };
-struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; float* st = nullptr; int nsub = 0; float* amax = nullptr; int srows = 1;
-                GnPre pre[2]; int npre = 0; };
-// a GroupNorm that will normalise [the tensor a launch is about to produce | b] (b may be null); want_bound: for an fp16x2 consumer
-struct GnHint { const float* gamma; const float* beta; const Tensor* b; bool want_bound; };
-struct GnHints { GnHint h[2]; int n = 0; void add(const GnHint& x) { if (n < 2) h[n++] = x; } };
+struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; float* st = nullptr; int nsub = 0; float* amax = nullptr; int srows = 1; };
 
 struct ConvW {            // one convolution's parameters on the device
   const float* oihw = nullptr;   // [cout][cin][ks][ks] (for NIN: transposed copy)
@@ -259,6 +252,8 @@ struct ConvW {            // one convolution's parameters on the device
                                        // 3x3 with cout % 128 == 0, cin % 16 == 0
   const float* split_scale = nullptr;  // fp16x2: device scalar 2^-(k+4) behind the packed fragments
   int split_mode = 0;                  // 1 bf16x3, 2 fp16x2 (0: no split layout)
+  const float* packed_wino = nullptr;  // Winograd F(2,3) x fp16x2 fragment layout (kernels_conv_wino.h), 3x3 with cout % 128 == 0, cin % 16 == 0
+  const float* wino_scale = nullptr;   // ... and the per-output-channel factors behind it
   const float* bias = nullptr;
   int ks = 1, cin = 0, cout = 0, co_t = 0;
 };
@@ -516,7 +511,6 @@ class Engine {
   int last_nfe() const { return nfe_; }
   int graph_captures() const { return graph_captures_; }     // how many times a step was captured + instantiated (tests, bench)
   int graph_updates() const { return graph_updates_; }       // ... captured and applied to the existing executable in place
-  int gn_tail_jobs() const { return fin_count_; }            // GroupNorm finalize jobs of the planned forward that run in convolution tails
   int split_mode() const { return split_mode_; }
   size_t arena_bytes() const { return arena_cap_; }
 
@@ -553,7 +547,18 @@ class Engine {
     a.src1 = x; a.src2 = x2; a.C1 = Cin - C2; a.C2 = C2; a.bias = bias; a.res = res; a.out_scale = out_scale; a.out = out;
     a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
-    if (force_direct == 2 || force_direct == 3) {          // the split kernels: 2 bf16x3, 3 fp16x2
+    if (force_direct == 4 || force_direct == 5) {          // Winograd F(2,3) x fp16x2: 4 = 8-row shape, 5 = 4-row shape
+      SG_REQUIRE(ks == 3 && conv_wino_eligible(a.C1, C2, Cout, W), "op_conv2d: shape is not eligible for the Winograd kernel");
+      const float* pk = pack_wino(w_oihw, Cin, Cout, false, &a.co_scale);
+      a.w = pk;
+      float* bounds = input_bounds(x, a.C1, x2, C2, B, H * W);
+      const float* am2 = x2 ? bounds + (size_t)B * kAmaxSpread : nullptr;
+      float* xb = producer_bound(in_scale, in_shift, Cin, bounds, am2, B);
+      a.xbound = xb;
+      launch_conv_wino(a, stream_, force_direct == 5);
+      SG_CHECK(drt::stream_sync(stream_));
+      free_tmp(const_cast<float*>(pk)); free_tmp(bounds); free_tmp(xb);
+    } else if (force_direct == 2 || force_direct == 3) {          // the split kernels: 2 bf16x3, 3 fp16x2
       SG_REQUIRE(conv_split_eligible(ks, a.C1, C2, Cout) || conv_thin_split_eligible(ks, a.C1, C2, Cout),
                  "op_conv2d: shape is not eligible for the split kernels");
       const int smode = force_direct - 1;
@@ -665,15 +670,17 @@ class Engine {
     int ablate = 0, abl_split = 0, stag = -1, stag_mode = 0;
     bool split_rows4 = false;
     if (variant >= 0) {
-      stag = (variant >> 24) & 127;              // measurement knob: start-up stagger of the split 3x3 kernel, units per phase step
+      stag = (variant >> 24) & 127;              // measurement knob: start-up stagger of the Winograd kernel, sleep units per phase step
       stag_mode = (variant >> 22) & 1;
       split_rows4 = (variant >> 23) & 1;         // measurement knob: 4-row workgroup shape of the split 3x3 kernel
       abl_split = (variant >> 12) & 1023;        // measurement knob: compile-time variant of the split 3x3 kernel, bits 12..21
       if (!(variant & (64 | 128))) { ablate = abl_split & 15; abl_split = 0; }   // fp32 kernels: run-time ablation bits 12..15
       variant &= 4095;
     }
+    const bool wino = variant >= 0 && (variant & 1024);          // measurement: the Winograd F(2,3) x fp16x2 kernel (bit 23: its 4-row shape)
     const int smode = variant < 0 ? 0 : ((variant & 128) ? 2 : ((variant & 64) ? 1 : 0));
-    const bool b3 = smode != 0;
+    const bool b3 = smode != 0 && !wino;
+    SG_REQUIRE(!wino || (ks == 3 && conv_wino_eligible(Cin, 0, Cout, W)), "bench_conv: shape is not eligible for the Winograd kernel");
     SG_REQUIRE(!b3 || conv_split_eligible(ks, Cin, 0, Cout), "bench_conv: shape is not eligible for the split kernels");
     const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * Cout * H * W, nw = (size_t)Cout * Cin * ks * ks;
     const size_t ne = packed_weight_elems(ks, Cin, Cout, pl.co_t);
@@ -710,7 +717,13 @@ class Engine {
         }
       }
     }
-    a.stagger_units = stag > 0 ? stag : 0; a.stagger_mode = stag_mode; a.stagger_slots = split_rows4 ? 768 : 512;
+    if (wino) {
+      pk3 = pack_wino(w, Cin, Cout, false, &a.co_scale); a.w = pk3;
+      bounds = input_bounds(x, Cin, nullptr, 0, B, H * W);
+      xbound = producer_bound(a.in_scale, a.in_shift, Cin, bounds, nullptr, B); a.xbound = xbound;
+    }
+    a.stagger = stag > 0 ? stag : 0;
+    (void)stag_mode;
     unsigned long long* trace_dev = nullptr;
     const size_t n_wg = (size_t)B * ((H + 7) / 8) * ((W + 31) / 32) * ((Cout + 127) / 128);
     if (abl_split & 64) {
@@ -718,7 +731,11 @@ class Engine {
       SG_CHECK(drt::memset_dev(trace_dev, 0, n_wg * 128, stream_));
       a.trace = trace_dev;
     }
-    auto go = [&]() { if (b3) launch_conv_split(a, ks, smode, stream_, split_rows4, abl_split); else launch_conv_mfma(a, ks, pl, stream_, variant); };
+    auto go = [&]() {
+      if (wino) launch_conv_wino(a, stream_, split_rows4, (abl_split & 64) != 0);
+      else if (b3) launch_conv_split(a, ks, smode, stream_, split_rows4, abl_split);
+      else launch_conv_mfma(a, ks, pl, stream_, variant);
+    };
     for (int i = 0; i < 2; ++i) go();
     drt::event_record(&e0, stream_);
     for (int i = 0; i < iters; ++i) go();
@@ -868,6 +885,8 @@ class Engine {
       c.split_mode = split_mode_;
       c.packed_split = pack_split(c.oihw, ks, cin, cout, c.split_mode, true, &c.split_scale);
     }
+    // the wide levels run these layers on the Winograd F(2,3) x fp16x2 kernel (conv(): use_wino)
+    if (split_mode_ == 2 && wino_ && ks == 3 && conv_wino_eligible(cin, 0, cout, 2)) c.packed_wino = pack_wino(c.oihw, cin, cout, true, &c.wino_scale);
     return c;
   }
 
@@ -891,6 +910,21 @@ class Engine {
       DRT_LAUNCH(pack_weights_split_kernel<SplitB3>, grid, dim3(256), stream_, pa);
       *scale_out = nullptr;
     }
+    return reinterpret_cast<const float*>(pk);
+  }
+
+  // weights in the fragment order of conv3x3_wino_kernel: transformed along the kernel's columns in fp64, scaled per output channel
+  const float* pack_wino(const float* oihw, int cin, int cout, bool weight_owned, const float** scale_out) {
+    const size_t frags = packed_wino_frags(cin, cout);
+    const int cout_pad = (cout + 127) / 128 * 128;
+    const size_t bytes = packed_wino_bytes(cin, cout) + (size_t)cout_pad * 4;       // [fragments][inverse scales][scales (packing scratch)]
+    uint32_t* pk = static_cast<uint32_t*>(weight_owned ? dev_alloc_w(bytes) : dev_alloc_tmp(bytes));
+    float* inv = reinterpret_cast<float*>(pk) + frags * 4;
+    float* sc = inv + cout_pad;
+    DRT_LAUNCH(wino_co_scale_kernel, dim3((unsigned)((cout_pad + 255) / 256)), dim3(256), stream_, oihw, cin, cout, cout_pad, inv, sc);
+    PackWinoArgs pa{oihw, pk, cin, cout, frags};
+    DRT_LAUNCH(pack_weights_wino_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), stream_, pa, (const float*)sc);
+    *scale_out = inv;
     return reinterpret_cast<const float*>(pk);
   }
 
@@ -987,7 +1021,6 @@ class Engine {
       invalidate_graph();
       cur_F_ = F;
       if (ragged()) build_rag_tables(B, F, T);
-      if (!fin_dev_) fin_dev_ = static_cast<GnFin*>(dev_alloc(sizeof(GnFin) * kMaxFin));
       // size the arena by a dry run
       arena_.measure_mode();
       dry_ = true;
@@ -1016,7 +1049,6 @@ class Engine {
         amax_pool_ = static_cast<float*>(dev_alloc(need_amax * 4));
         amax_pool_floats_ = need_amax;
       }
-      plan_gn_tails(B, F, T);
       if (!step_ctr_) step_ctr_ = static_cast<int*>(dev_alloc(256));
       if (!lang_scal_) lang_scal_ = static_cast<float*>(dev_alloc(256));
       if (lang_partial_) dev_free_owned(lang_partial_);
@@ -1090,6 +1122,12 @@ class Engine {
     const int l = level_of(H);
     return Rag{rag_w_dev_.at(l), rag_off_dev_.at(l), rag_soff_dev_.at(l)};
   }
+  bool rag_all_mult2(int H) const {
+    if (!ragged()) return true;
+    const int l = level_of(H);
+    for (int t : rag_T_) if ((t >> l) % 2) return false;
+    return true;
+  }
   bool rag_all_mult4(int H) const {
     if (!ragged()) return true;
     const int l = level_of(H);
@@ -1148,15 +1186,6 @@ class Engine {
   void gn_coeffs(const Tensor& a, const Tensor* b, const float* gamma, const float* beta, float** sc, float** sh,
                  const float** bound = nullptr) {
     const int C = a.C + (b ? b->C : 0), HW = a.H * a.W;
-    for (int k = 0; k < a.npre; ++k) {        // already computed by the tail of the launch that produced `a` (conv, GnHint)
-      const GnPre& pr = a.pre[k];
-      if (pr.gamma == gamma && pr.other == (b ? b->p : nullptr) && (!bound || pr.bound)) {
-        *sc = pr.sc; *sh = pr.sh;
-        if (bound) *bound = pr.bound;
-        --pre_pending_;
-        return;
-      }
-    }
     float* bslot = bound ? next_amax() : nullptr;
     if (bound) *bound = bslot;
     const float* st[2] = {a.st, b ? b->st : nullptr};
@@ -1203,8 +1232,7 @@ class Engine {
   }
 
   Tensor conv(const ConvW& w, const Tensor& a, const Tensor* b, const Xform& xf, const float* bias, const float* bias2,
-              const float* res, float out_scale, const FwdCtl& ctl, bool emit_stats = false, const Shortcut* sc = nullptr,
-              const GnHints* hints = nullptr) {
+              const float* res, float out_scale, const FwdCtl& ctl, bool emit_stats = false, const Shortcut* sc = nullptr) {
     const int Cin = a.C + (b ? b->C : 0);
     SG_REQUIRE(Cin == w.cin, "conv: channel mismatch");
     Tensor o = new_tensor(w.cout, a.H, a.W);
@@ -1246,6 +1274,13 @@ class Engine {
                         // raw residual stream and scale by the producers' range bounds; either must be known
                         (w.split_mode != 2 || (w.ks == 3 ? xf.bound != nullptr
                                                          : (xf.scale == nullptr && a.amax && (!b || b->amax)))));
+    // The wide levels (>= wino_min_tiles_ tiles per nominal image: 64 x 128 and up) run the full 3x3 blocks on the Winograd F(2,3) x
+    // fp16x2 kernel: 2/3 of the matrix work of the direct split kernel, which is bound by the energy of its MFMAs (kernels_conv_wino.h).
+    // Decided per layer and level like every kernel family; its 4-row shape (launches that cannot fill the chip) gives the same bits.
+    const bool use_wino = use_split && !coarse_split && wino_ && w.packed_wino && w.ks == 3 && w.split_mode == 2 && xf.bound != nullptr &&
+                          conv_wino_eligible(a.C, b ? b->C : 0, w.cout, 2) && level_of(a.H) <= 5 && tiles8 >= wino_min_tiles_;
+    // (the kernel stages aligned column pairs: frame counts are multiples of 64, so every utterance's width is even down to level 5)
+    SG_REQUIRE(!use_wino || (a.W % 2 == 0 && (!ragged() || rag_all_mult2(a.H))), "conv: odd width on a Winograd level");
     // Coarse levels (at most 512 pixels per nominal image) on the fp32 kernels: 32-channel tiles with CHUNKED accumulation (decided per
     // layer and image, never by the batch: it fixes the summation order), and -- when even those tiles leave most CUs idle
     // (small batches) -- the chunks spread over workgroups (split-K, bit-identical): a K loop of 32-64 serial stages was the
@@ -1289,59 +1324,8 @@ class Engine {
       o.st = arena_.alloc((size_t)B_ * w.cout * 2);
     }
     o.amax = next_amax();
-    // GroupNorm coefficients of the consumers named by `hints`, computed by the last workgroup of each utterance in THIS launch
-    // (ConvArgs::fin, conv_gn_tail) instead of a gn_finalize_kernel launch behind it -- for tensors whose partials one workgroup
-    // sums in a few microseconds (gn_tail_max_pairs_ per utterance: the levels from 32 x 64 down, where a launch costs more than
-    // the sum).  The jobs live in a device table written by the planning pass (plan_gn_tails); this run hands out the same
-    // entries in the same order.
-    const GnFin* fin_dev = nullptr; int nfin = 0; float* fin_ctr = nullptr;
-    // (not in ragged launches: the full-width five-utterance case of test_ragged_batch_gives_every_utterance_its_single_run_bits
-    // faulted on the GPU with the tails on -- at the 4 x 8 level, utterance widths 8 / 1 / 3 / 5 / 2 -- while the same composition
-    // runs clean on the emulator under AddressSanitizer; unresolved, and the mechanism is off by default anyway)
-#ifdef SGMSE_TAIL_IN_RAGGED          // (debugging the fault described above: tails in ragged launches too)
-    const bool tail_ok = true;
-#else
-    const bool tail_ok = !ragged();
-#endif
-    if (hints && gn_tail_ && tail_ok && o.st && o.nsub >= 1 && use_mfma && !(use_split && w.ks == 1)) {   // (conv1x1_split_kernel has no tail)
-      for (int k = 0; k < hints->n; ++k) {
-        const GnHint& hn = hints->h[k];
-        const Tensor* hb = hn.b;
-        if (hb && !hb->st) continue;                                       // (would need a statistics pass first)
-        const long pairs = (long)w.cout * o.nsub + (hb ? (long)hb->C * hb->nsub : 0L);
-        if (pairs > gn_tail_max_pairs_) continue;
-        const int C = w.cout + (hb ? hb->C : 0);
-        GnPre pr;
-        pr.gamma = hn.gamma; pr.other = hb ? hb->p : nullptr;
-        pr.sc = arena_.alloc((size_t)B_ * C); pr.sh = arena_.alloc((size_t)B_ * C);
-        float* bslot = hn.want_bound ? next_amax() : nullptr;
-        pr.bound = bslot;
-        const int idx = fin_next_++;
-        if (plan_) {
-          SG_REQUIRE(idx < kMaxFin, "GroupNorm tail table full");
-          fin_host_[idx] = GnFin{o.st, hb ? hb->st : nullptr, o.amax, hb ? hb->amax : nullptr, hn.gamma, hn.beta, pr.sc, pr.sh, bslot,
-                                 rag_of(a.H), w.cout, o.nsub, o.srows, hb ? hb->C : 0, hb ? hb->nsub : 0, hb ? hb->srows : 1,
-                                 std::min(C / 4, 32), a.H * a.W, a.H, 1e-6f};
-        }
-        if (nfin == 0) fin_dev = fin_dev_ + idx;
-        ++nfin;
-        o.pre[o.npre++] = pr;
-        ++pre_pending_;
-      }
-      if (nfin) fin_ctr = next_amax();
-    }
-    // split-K: one arrival counter per (tile, channel block); the last chunk workgroup of a tile reduces and finishes it
-    // (ConvArgs::splitk_ctr) instead of a conv_splitk_reduce_kernel launch
-    unsigned* splitk_ctr = nullptr;
-    if (ksplit > 1 && splitk_fused_ && !coarse_split) {        // (the fp32 kernels' small tiles; the chunked fp16x2 kernel keeps its reduce launch)
-      const long nctr = (long)B_ * ((a.H + rows_ - 1) / rows_) * ((a.W + 31) / 32) * ((w.cout + co_t - 1) / co_t);
-      splitk_ctr = reinterpret_cast<unsigned*>(next_amax());
-      for (long have = (long)B_ * kAmaxSpread; have < nctr; have += (long)B_ * kAmaxSpread) (void)next_amax();   // (consecutive slots are contiguous)
-    }
     if (dry_) { if (partial) arena_.release(partial); return o; }
     ConvArgs ca{};
-    ca.fin = fin_dev; ca.nfin = nfin; ca.fin_ctr = reinterpret_cast<unsigned*>(fin_ctr); ca.fin_mode = nfin ? gn_tail_mode_ : 0;
-    ca.splitk_ctr = splitk_ctr;
     ca.xcd_map = conv_xcd_map_ ? 1 : 0;
     ca.stats_out = o.st; ca.stats_nsub = o.nsub; ca.stats_rows = o.srows;
     ca.amax_out = o.amax;
@@ -1375,18 +1359,16 @@ class Engine {
       const long nblk8 = (long)B_ * ((a.H + 7) / 8) * ((a.W + 31) / 32) * ((w.cout + 127) / 128);
       const bool rows4 = coarse_split || nblk8 < tile_min_blocks_;
       if (coarse_split) { ca.kchunk_stages = kchunk; ca.partial = partial; }
-      // start-up stagger (ConvArgs::stagger_units): only for launches of several residency rounds, where the one-time fill
-      // is small against what the de-phased rounds gain
-      const long slots = rows4 ? 768 : 512;
-      if (w.ks == 3 && split_stagger_ > 0 && (rows4 ? 2 * nblk8 : nblk8) >= 4 * slots) {
-        ca.stagger_units = (int)std::max(1L, (long)(Cin / 16) * split_stagger_ / 16 / 8128);
-        ca.stagger_slots = (int)slots; ca.stagger_mode = split_stagger_mode_;
+      if (use_wino) {
+        ca.w = w.packed_wino; ca.co_scale = w.wino_scale; ca.acc_scale = nullptr;
+        launch_conv_wino(ca, stream_, nblk8 < tile_min_blocks_);   // one 512-thread workgroup per CU: the 8-row shape from two rounds of the chip
+      } else {
+        launch_conv_split(ca, w.ks, w.split_mode, stream_, rows4, 0, ksplit);
       }
-      launch_conv_split(ca, w.ks, w.split_mode, stream_, rows4, 0, ksplit);
       if (coarse_split && partial) arena_.release(partial);
       if (noting())
-        snprintf(prof_note_, sizeof prof_note_, "conv3x3-split %d->%d @%dx%dx%d%s%s%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "",
-                 sc ? " +shortcut" : "", ca.rag_cols ? " existing-tiles" : "");
+        snprintf(prof_note_, sizeof prof_note_, "conv3x3-%s %d->%d @%dx%dx%d%s%s%s%s", use_wino ? "wino" : "split", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "",
+                 xf.scale ? " +gn" : "", sc ? " +shortcut" : "", ca.rag_cols ? " existing-tiles" : "");
       tick(w.ks == 3 ? (w.cout >= 128 ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else if (use_mfma) {
       ConvPlan pl{co_t, rows_, true};
@@ -1446,10 +1428,8 @@ class Engine {
   }
 
   // ResnetBlockBigGANpp.forward (layerspp.py:242-274).  Inputs stay owned by the caller.
-  // out_hints: the GroupNorm(s) that will consume this block's output (finished in the tail of its last convolution)
-  Tensor res_block(const Mod& m, Tensor& a, Tensor* b, const FwdCtl& ctl, const GnHints* out_hints = nullptr) {
+  Tensor res_block(const Mod& m, Tensor& a, Tensor* b, const FwdCtl& ctl) {
     const ResW& r = res_.at(m.idx);
-    GnHints g1; g1.add(GnHint{r.g1w, r.g1b, nullptr, true});       // GroupNorm_1 reads Conv_0's output
     float *sc0, *sh0, *sc1, *sh1;
     const float *bd0, *bd1;
     gn_coeffs(a, b, r.g0w, r.g0b, &sc0, &sh0, &bd0);
@@ -1461,10 +1441,10 @@ class Engine {
       SG_REQUIRE(b == nullptr, "resample block with concat input");
       Tensor hr = fir(a, m.up, x0, &xs);
       have_xs = true;
-      h = conv(r.c0, hr, nullptr, Xform{nullptr, nullptr, 0, bd0}, nullptr, temb, nullptr, 1.f, ctl, true, nullptr, &g1);
+      h = conv(r.c0, hr, nullptr, Xform{nullptr, nullptr, 0, bd0}, nullptr, temb, nullptr, 1.f, ctl, true);
       drop(hr);
     } else {
-      h = conv(r.c0, a, b, x0, nullptr, temb, nullptr, 1.f, ctl, true, nullptr, &g1);
+      h = conv(r.c0, a, b, x0, nullptr, temb, nullptr, 1.f, ctl, true);
     }
     arena_.release(sc0); arena_.release(sh0);
     gn_coeffs(h, nullptr, r.g1w, r.g1b, &sc1, &sh1, &bd1);
@@ -1477,15 +1457,15 @@ class Engine {
       if (runs_on_h2_split3(r.c1, h.C, h.H, dec_W(h.H)) && shortcut_foldable(r.c2, sa, sb)) {
         // (Conv_1(h) + Conv_2(x)) / sqrt 2 as one accumulation: the shortcut's K-stages run inside the 3x3 launch
         const Shortcut scin{&r.c2, &sa, sb};
-        out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, nullptr, inv_sqrt2, ctl, true, &scin, out_hints);
+        out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, nullptr, inv_sqrt2, ctl, true, &scin);
       } else {
         Tensor sh_t = conv(r.c2, sa, sb, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl);
-        out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, sh_t.p, inv_sqrt2, ctl, true, nullptr, out_hints);
+        out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, sh_t.p, inv_sqrt2, ctl, true);
         drop(sh_t);
       }
     } else {
       SG_REQUIRE(b == nullptr, "identity shortcut with concat input");
-      out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, a.p, inv_sqrt2, ctl, true, nullptr, out_hints);
+      out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, a.p, inv_sqrt2, ctl, true);
     }
     if (have_xs) drop(xs);
     drop(h);
@@ -1494,7 +1474,7 @@ class Engine {
   }
 
   // AttnBlockpp.forward (layerspp.py:75-91)
-  Tensor attn_block(const Mod& m, Tensor& x, const FwdCtl& ctl, const GnHints* out_hints = nullptr) {
+  Tensor attn_block(const Mod& m, Tensor& x, const FwdCtl& ctl) {
     const AttnW& w = attn_.at(m.idx);
     float *sc, *sh;
     gn_coeffs(x, nullptr, w.gw, w.gb, &sc, &sh);
@@ -1509,7 +1489,7 @@ class Engine {
       tick(TC_ATTN, 4.0 * B_ * (double)x.C * (x.H * x.W) * (double)(x.H * x.W));
     }
     drop(qkv);
-    Tensor out = conv(w.proj, o, nullptr, Xform{}, w.proj.bias, nullptr, x.p, 0.70710678118654752440f, ctl, true, nullptr, out_hints);
+    Tensor out = conv(w.proj, o, nullptr, Xform{}, w.proj.bias, nullptr, x.p, 0.70710678118654752440f, ctl, true);
     drop(o);
     return out;
   }
@@ -1528,7 +1508,6 @@ class Engine {
     B_ = B;
     cur_F_ = F;
     amax_next_ = 0;
-    fin_next_ = 0; pre_pending_ = 0;
     if (!dry_ && poison_ && arena_base_) SG_CHECK(drt::memset_dev(arena_base_, 0xFF, arena_cap_, stream_));
     if (!dry_ && amax_pool_) {
       const int n = amax_slots_ * B * kAmaxSpread;
@@ -1540,30 +1519,6 @@ class Engine {
     auto next = [&]() -> const Mod& { SG_REQUIRE(mi < layout_.size(), "layout exhausted"); return layout_[mi++]; };
     const int FT = F * T;
     std::vector<Tensor> hs;
-    // The GroupNorm(s) that read the tensor the module before layout_[mi] is about to produce, from the modules that follow it:
-    // a ResBlock's GroupNorm_0 (over [the tensor | the next skip tensor] on the way up: a block whose input is wider than the
-    // tensor), an attention block's GroupNorm, or the output pyramid's GroupNorm followed by the up-sampling block's.  (A
-    // Combine or a plain convolution normalises nothing.)  What is named here is computed in the tail of the producing launch;
-    // what is not is computed by gn_finalize_kernel when the consumer asks (gn_coeffs) -- the same numbers either way.
-    auto hints_for = [&](int C) -> GnHints {
-      GnHints g;
-      if (mi >= layout_.size()) return g;
-      const Mod& f = layout_[mi];
-      auto res0 = [&](const Mod& r, bool allow_concat) {
-        const ResW& w = res_.at(r.idx);
-        const bool concat = r.cin != C;
-        if (concat && !(allow_concat && !hs.empty() && hs.back().C + C == r.cin)) return;
-        g.add(GnHint{w.g0w, w.g0b, concat ? &hs.back() : nullptr, true});
-      };
-      if (f.kind == Mod::RES) res0(f, true);
-      else if (f.kind == Mod::ATTN) g.add(GnHint{attn_.at(f.idx).gw, attn_.at(f.idx).gb, nullptr, false});
-      else if (f.kind == Mod::GN) {
-        g.add(GnHint{gn_.at(f.idx).first, gn_.at(f.idx).second, nullptr, true});
-        if (mi + 2 < layout_.size() && layout_[mi + 2].kind == Mod::RES) res0(layout_[mi + 2], false);
-      }
-      return g;
-    };
-
     Tensor xr = new_tensor(4, F, T);
     const bool entry8 = entry_mfma_ && entry8_.packed && layout_[mi].idx == entry8_idx_;
     Tensor xr8{};
@@ -1575,8 +1530,7 @@ class Engine {
     {
       const Mod& m = next();
       const ConvW& w = entry8 ? entry8_ : conv_.at(m.idx);
-      const GnHints g = hints_for(w.cout);
-      hs.push_back(conv(w, entry8 ? xr8 : xr, nullptr, Xform{}, w.bias, nullptr, nullptr, 1.f, ctl, true, nullptr, &g));
+      hs.push_back(conv(w, entry8 ? xr8 : xr, nullptr, Xform{}, w.bias, nullptr, nullptr, 1.f, ctl, true));
       if (entry8) drop(xr8);
     }
     Tensor pyr_in = xr;   // input pyramid (ncsnpp.py:293-296); released at the end / when replaced
@@ -1584,16 +1538,14 @@ class Engine {
     for (int l = 0; l < L; ++l) {
       for (int rb = 0; rb < c.num_res_blocks; ++rb) {
         const Mod& m = next();
-        GnHints g = hints_for(m.cout);
-        Tensor h = res_block(m, hs.back(), nullptr, ctl, &g);
+        Tensor h = res_block(m, hs.back(), nullptr, ctl);
         // the reference's forward places attention by the ACTUAL height (ncsnpp.py:308) while its module list was built from the
         // configured image_size (ncsnpp.py:189-193): an input of another height runs off the list there (TypeError); say why
         SG_REQUIRE(cfg_has_attn(c, h.H) == cfg_has_attn(c, c.image_size >> l),
                    "input height does not match the image_size the network was built for (attention placement, ncsnpp.py:308)");
         if (cfg_has_attn(c, h.H)) {
           const Mod& ma = next();
-          g = hints_for(ma.cin);
-          Tensor h2 = attn_block(ma, h, ctl, &g);
+          Tensor h2 = attn_block(ma, h, ctl);
           drop(h);
           h = h2;
         }
@@ -1601,8 +1553,7 @@ class Engine {
       }
       if (l != L - 1) {
         const Mod& m = next();
-        const GnHints g = hints_for(m.cout);
-        Tensor h = res_block(m, hs.back(), nullptr, ctl, &g);
+        Tensor h = res_block(m, hs.back(), nullptr, ctl);
         if (c.progressive_input == 1) {
           const Mod& mc = next();
           Tensor np = fir(pyr_in, false, Xform{});
@@ -1621,17 +1572,16 @@ class Engine {
 
     Tensor h = hs.back();   // not popped: still referenced by the skip stack (ncsnpp.py:337)
     {
-      const Mod& m1 = next(); GnHints g = hints_for(m1.cout); Tensor a = res_block(m1, h, nullptr, ctl, &g);
-      const Mod& m2 = next(); g = hints_for(m2.cin); Tensor b2 = attn_block(m2, a, ctl, &g); drop(a);
-      const Mod& m3 = next(); g = hints_for(m3.cout); h = res_block(m3, b2, nullptr, ctl, &g); drop(b2);
+      const Mod& m1 = next(); Tensor a = res_block(m1, h, nullptr, ctl);
+      const Mod& m2 = next(); Tensor b2 = attn_block(m2, a, ctl); drop(a);
+      const Mod& m3 = next(); h = res_block(m3, b2, nullptr, ctl); drop(b2);
     }
     Tensor pyramid; bool have_pyr = false;
     for (int l = L - 1; l >= 0; --l) {
       for (int rb = 0; rb < c.num_res_blocks + 1; ++rb) {
         const Mod& m = next();
         Tensor skip = hs.back(); hs.pop_back();
-        const GnHints g = hints_for(m.cout);
-        Tensor o = res_block(m, h, &skip, ctl, &g);
+        Tensor o = res_block(m, h, &skip, ctl);
         drop(h); drop(skip);
         h = o;
       }
@@ -1639,8 +1589,7 @@ class Engine {
                  "input height does not match the image_size the network was built for (attention placement, ncsnpp.py:354)");
       if (cfg_has_attn(c, h.H)) {
         const Mod& ma = next();
-        const GnHints g = hints_for(ma.cin);
-        Tensor h2 = attn_block(ma, h, ctl, &g);
+        Tensor h2 = attn_block(ma, h, ctl);
         drop(h); h = h2;
       }
       if (c.progressive == 1) {
@@ -1658,8 +1607,7 @@ class Engine {
       }
       if (l != 0) {
         const Mod& m = next();
-        const GnHints g = hints_for(m.cout);
-        Tensor o = res_block(m, h, nullptr, ctl, &g);
+        Tensor o = res_block(m, h, nullptr, ctl);
         drop(h); h = o;
       }
     }
@@ -1677,8 +1625,6 @@ class Engine {
       drop(h);
     }
     SG_REQUIRE(mi == layout_.size(), "forward did not consume every module");
-    SG_REQUIRE(pre_pending_ == 0, "internal: GroupNorm coefficients were prepared for a consumer that never asked for them");
-    SG_REQUIRE(dry_ || fin_next_ == fin_count_, "internal: GroupNorm tail jobs differ from the planned ones");
     if (!dry_) {
       ExitArgs ea{h4.p, Wp("output_layer.weight"), Wp("output_layer.bias"), ctl.tvals, ctl.t_bstride, ctl.t_sstride, ctl.step_ptr,
                   c.variant == 1 ? 1 : 0, c.scale_by_sigma,
@@ -1772,14 +1718,16 @@ class Engine {
     e = getenv("SGMSE_SPLIT_MIN_TILES");
     split_min_tiles_ = e ? atol(e) : 8L;                    // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
-    e = getenv("SGMSE_SPLIT_STAGGER");                   // start-up stagger of the split 3x3 kernel: cycles per K-stage of a tile (0: off)
-    split_stagger_ = e ? atol(e) : SGMSE_SPLIT_STAGGER_DEFAULT;
-    e = getenv("SGMSE_SPLIT_STAGGER_MODE");
-    split_stagger_mode_ = e ? atoi(e) : 0;
     coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);
     poison_ = flag("SGMSE_POISON", false);
-    rag_prefix_ = flag("SGMSE_RAGGED_PREFIX", false);       // ragged convolution launches over the tiles that exist (ConvArgs::rag_cols): built, bit-identical, not yet measured
-    conv_xcd_map_ = flag("SGMSE_CONV_XCD_MAP", false);      // XCD-aware tile order of the convolution kernels (ConvArgs::xcd_map): built, bit-identical, not yet measured
+    // ragged convolution launches over the tiles that exist (ConvArgs::rag_cols) and the XCD-aware tile order of the convolution
+    // kernels (ConvArgs::xcd_map): both bit-identical, both measured in round 4 (profiles/r04_knobs_ab.txt: ragged batches 1.15 -> 1.04x
+    // per frame; +3.5-4 % at T = 512 and T = 448) and on since
+    rag_prefix_ = flag("SGMSE_RAGGED_PREFIX", true);
+    conv_xcd_map_ = flag("SGMSE_CONV_XCD_MAP", true);
+    wino_ = flag("SGMSE_WINO", true);                       // Winograd F(2,3) x fp16x2 kernel on the wide levels (0: the direct fp16x2 split kernel there too)
+    e = getenv("SGMSE_WINO_MIN_TILES");
+    wino_min_tiles_ = e ? atol(e) : 32L;                    // ... from this many 8 x 32 tiles per nominal image (32: the 64 x 128 level and up)
     debug_sync_ = flag("SGMSE_DEBUG_SYNC", false);          // synchronise after every launch of the forward and print its label (stderr)
     entry_mfma_ = flag("SGMSE_ENTRY_MFMA", true);           // entry convolution on the fp32 MFMA kernel (input channels padded to 8)
     fold_shortcut_ = flag("SGMSE_FOLD_SHORTCUT", true);
@@ -1792,20 +1740,6 @@ class Engine {
     chunk_min_width_ = e ? atoi(e) : 32;                    //     (profiles/r02_chunk_splitk.txt)
     e = getenv("SGMSE_COARSE_SPLITK_DIV");                  // ... whose chunks go to separate workgroups below tile_min_blocks / this
     coarse_splitk_div_ = e ? atol(e) : 4L;                  //     (batch 1: 0.503 -> 0.457 s per utterance, profiles/r02_chunk_splitk.txt)
-    // Work finished by the LAST workgroup to arrive instead of by a second launch -- GroupNorm coefficients in the tail of the
-    // producing convolution (conv_gn_tail), split-K reduce + epilogue by the last chunk workgroup of a tile (ConvArgs::splitk_ctr).
-    // Both are bit-identical to the two-launch form and both are OFF: the dependent step costs more as a serial tail of ONE
-    // workgroup (8 GroupNorm groups per wave, each loads -> fp64 tree -> sqrt / divide -> stores: ~ +19 us on the launch) than as
-    // a launch of its own, 32 workgroups wide (7.7 us) -- whatever the arrival does to the caches.  Batch 1: 0.4565 s per
-    // utterance without, 0.478 s with the fused split-K, 0.529 s with the tails, 0.547 s with both (release per workgroup,
-    // acquire in the last); 0.543 vs 0.472 s with device-coherent accesses and no cache maintenance (SGMSE_GN_TAIL_MODE=1); batch
-    // 32: 5.11 / 4.94 / 4.80 utt/s (profiles/r03_arrive_last_ab.txt, r03_tail_mode1_ab.txt).
-    gn_tail_ = flag("SGMSE_GN_TAIL", false);
-    splitk_fused_ = flag("SGMSE_SPLITK_FUSED", false);
-    e = getenv("SGMSE_GN_TAIL_MODE");                       // 0: release / acquire fences around plain accesses; 1 (experimental): device-coherent
-    gn_tail_mode_ = e ? atoi(e) : 0;                        //    accesses to the partial sums, no cache maintenance (ConvArgs::fin_mode)
-    e = getenv("SGMSE_GN_TAIL_MAX_PAIRS");                  // ... for tensors of at most this many partial pairs per utterance
-    gn_tail_max_pairs_ = e ? atol(e) : 8192L;
   }
   // per-forward range-bound slots ([B][kAmaxSpread] floats each), handed out in program order; counted by the dry run
   float* amax_pool_ = nullptr; size_t amax_pool_floats_ = 0; int amax_slots_ = 0, amax_next_ = 0;
@@ -1813,36 +1747,15 @@ class Engine {
     const int i = amax_next_++;
     // dry run: a fake address (never dereferenced), non-null so that the kernel-family decisions that ask "is the bound known?"
     // come out as in the real run and the arena is sized for the launches that will really happen
-    if (dry_ && !plan_) return reinterpret_cast<float*>(uintptr_t(1) << 43) + (size_t)i * kAmaxSpread;
+    if (dry_) return reinterpret_cast<float*>(uintptr_t(1) << 43) + (size_t)i * kAmaxSpread;
     SG_REQUIRE(amax_pool_ && i < amax_slots_, "range-bound pool smaller than the forward needs");
     return amax_pool_ + (size_t)i * B_ * kAmaxSpread;
   }
-  // GroupNorm tails (conv, GnHint): the finalize jobs of one forward, in program order, on the host (written by the planning
-  // pass) and on the device (read by conv_gn_tail)
-  static constexpr int kMaxFin = 256;
-  std::vector<GnFin> fin_host_; GnFin* fin_dev_ = nullptr; int fin_next_ = 0, fin_count_ = 0, pre_pending_ = 0;
-  bool plan_ = false, gn_tail_ = false, splitk_fused_ = false; long gn_tail_max_pairs_ = 8192; int gn_tail_mode_ = 0;
-  void plan_gn_tails(int B, int F, int T) {
-    fin_host_.assign(kMaxFin, GnFin{});
-    arena_.reset();
-    dry_ = true; plan_ = true;
-    {
-      FwdCtl ctl{nullptr, 0, 0, nullptr, nullptr, 0, 0, 1.f};
-      run_forward(nullptr, 0, nullptr, 0, nullptr, B, F, T, ctl);
-    }
-    dry_ = false; plan_ = false;
-    fin_count_ = fin_next_;
-    if (fin_count_) {
-      SG_CHECK(drt::memcpy_h2d(fin_dev_, fin_host_.data(), sizeof(GnFin) * (size_t)fin_count_, stream_));
-      SG_CHECK(drt::stream_sync(stream_));
-    }
-    arena_.reset();
-  }
-  long tile_min_blocks_ = 512, split_min_tiles_ = 8, split_stagger_ = SGMSE_SPLIT_STAGGER_DEFAULT;
-  int split_stagger_mode_ = 0;
+  long tile_min_blocks_ = 512, split_min_tiles_ = 8;
   bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true, entry_mfma_ = true;
   ConvW entry8_{}; int entry8_idx_ = -1;
-  bool poison_ = false, debug_sync_ = false, conv_xcd_map_ = false, rag_prefix_ = false;
+  bool poison_ = false, debug_sync_ = false, conv_xcd_map_ = true, rag_prefix_ = true, wino_ = true;
+  long wino_min_tiles_ = 32;
   long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8, chunk_min_tiles_ = 2;
   int chunk_min_width_ = 32;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;

@@ -22,7 +22,8 @@
 // tile, 8-channel K-stages, next stage prefetched into registers during the MFMAs, two workgroups per CU.  Tried and
 // rejected (slower or equal): one workgroup per CU with a 512-register budget (-10 %), two half-size LDS stages with one
 // barrier per stage (-8 %, spills), 4 MFMA waves + 4 staging waves per workgroup (-17 %: one workgroup per CU exposes
-// every prologue/epilogue), iglp_opt(0) / s_setprio (0 %), start-up stagger of the second residency slot (0 %).
+// every prologue/epilogue), iglp_opt(0) / s_setprio (0 %), start-up stagger of the second residency slot (0 %); finishing a launch's dependent step
+// (GroupNorm coefficients, split-K reduce) in the last workgroup to arrive (+4-20 %, profiles/r03_arrive_last_ab.txt; removed in round 4).
 #pragma once
 #include <sgmse_devrt.h>
 #include <type_traits>
@@ -33,7 +34,6 @@ namespace sgmse {
 // first pixel in the packed plane sets (sum over the utterances before it of H * w), soff[b] = the same prefix over its GroupNorm
 // statistics sub-tiles (H * ceil(w / 32)).  w == nullptr: every utterance has the launch's W (uniform batch).
 struct Rag { const int* w; const long long* off; const long long* soff; };
-struct GnFin;
 
 struct ConvArgs {
   const float* src1; const float* src2;  // NCHW; virtual concat [src1 | src2] along C (src2 may be null)
@@ -47,6 +47,8 @@ struct ConvArgs {
   int in_act;              // 1: SiLU after the affine
   const float* res;        // residual [B][Cout][H][W] or null
   const float* acc_scale;  // device scalar multiplying the accumulator first (split kernels with pre-scaled operands), or null
+  int stagger;             // conv3x3_wino_kernel: start-up de-phasing of the first residency round, sleep units per phase step (0: off)
+  const float* co_scale;   // conv3x3_wino_kernel: per OUTPUT CHANNEL factor undoing the weights' power-of-two scale ([ceil(Cout/128)*128])
   float out_scale;         // out = (acc * acc_scale + bias + bias2 + res) * out_scale
   float* out;
   int Cout, B, H, W;
@@ -76,12 +78,6 @@ struct ConvArgs {
   // measurement-only ablation switches of the fp32 kernels for sgmse_bench_conv (results are then WRONG on purpose):
   // bit 2 stage only the first K-stage, bit 3 skip the barriers (the epilogue's switches are compile-time: conv_epilogue<ABL>)
   int ablate;
-  // Start-up stagger of the split 3x3 kernel (0: off).  Workgroups of the first residency round (linear id < stagger_slots)
-  // sleep phase * stagger_units * 8128 cycles, phase in 0..15, before they start: every workgroup of a launch takes the same
-  // time, so without it all resident workgroups stream their K-loops and then their epilogues in lockstep -- the matrix pipe
-  // idles while the whole chip reads residuals and writes outputs, and HBM idles during the K-loops
-  // (profiles/r02_split_ablation_microbench.txt: the phases add up instead of overlapping).
-  int stagger_units, stagger_slots, stagger_mode;
   // Folded residual shortcut of the split 3x3 kernel (ResnetBlockBigGANpp with a Conv_2, layerspp.py:266-274): out =
   // (Conv_1(act(GN(h))) + Conv_2(x)) / sqrt 2 is ONE accumulation -- the 1x1 shortcut runs as extra K-stages (centre tap only)
   // over the raw block input x in front of the 3x3 stages, instead of a separate launch that writes a tensor the 3x3 kernel
@@ -107,20 +103,6 @@ struct ConvArgs {
   int rag_vec_ok;             // ragged: every utterance's width is a multiple of 4 (float4 staging allowed)
   // measurement (ABL bit 6 instantiation): per workgroup {hw_id | xcc_id << 32, t_start, t_loop, t_epilogue, t_end} (shader clock)
   unsigned long long* trace;
-  // GroupNorm coefficients of this tensor's consumer(s), finished by the launch that produces the tensor (conv_gn_tail): the
-  // workgroup of an utterance that arrives LAST at the utterance's counter (fin_ctr[b * kAmaxSpread], zeroed by the engine with
-  // the range-bound pool) runs the nfin finalize jobs `fin` (device table; source 1 of each = this launch's stats_out) for that
-  // utterance -- what a gn_finalize_kernel launch behind this one would compute, bit for bit, without the launch.  Which
-  // workgroup does it varies, what it computes does not.  null: the engine launches gn_finalize_kernel itself.
-  const GnFin* fin; int nfin; unsigned* fin_ctr;
-  // fin_mode 0: the arrival is a device-scope release (every workgroup) / acquire (the last one) around plain accesses;
-  // 1 (experimental): this launch's partial sums are written and read with device-coherent accesses (drt_store_agent /
-  // drt_load_agent) and the arrival does no cache maintenance (drt_arrive_last_coherent)
-  int fin_mode;
-  // Split-K without a second launch: one arrival counter per (tile, channel block) of the launch (zeroed by the engine); the
-  // chunk workgroup of a tile that arrives LAST sums the tile's partial sums in chunk order and runs the epilogue itself -- what
-  // conv_splitk_reduce_kernel would do behind this launch, bit for bit.  null: the reduce kernel follows.
-  unsigned* splitk_ctr;
   // XCD-aware tile order (0: off, the default until measured).  Workgroups are dealt round-robin over the 8 XCDs by their linear
   // id and every XCD has its own L2: with the plain map a tile's vertical neighbour sits on the same XCD only when the tile row is a
   // multiple of 8 tiles long (T = 512: 16 tiles) -- other lengths fetch every halo row again (profiles/r03_length_sweep.txt: 3-4 %
@@ -187,15 +169,6 @@ __device__ __forceinline__ float amax_read(const float* amax, int b) {
   return m;
 }
 
-template <bool COH>
-__device__ __forceinline__ float amax_read_t(const float* amax, int b) {
-  const float* q = amax + b * kAmaxSpread + (threadIdx.x & (kAmaxSpread - 1));
-  float m = COH ? drt_load_agent(q) : *q;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  return m;
-}
-
 // exact power of two 2^k with m 2^k in [2^13, 2^14): the operand scale of the fp16x2 kernels for a tensor bounded by m
 __device__ __forceinline__ float h2_weight_scale(float absmax) {
   if (!(absmax > 0.f)) return 1.f;
@@ -220,8 +193,7 @@ struct GnFin {
 
 // The canonical order of a group's sum: 256 SLOTS, slot j takes the elements j, j + 256, ... (two pairs per 16-byte load where the
 // alignment allows) of source 1's share and then of source 2's, in fp64; the slots are then summed by the tree
-// slot[t] += slot[t + m], m = 128 ... 1.  gn_finalize_kernel runs a slot per thread, gn_finalize_group_wave four slots per lane:
-// the same additions in the same order.
+// slot[t] += slot[t + m], m = 128 ... 1 (gn_finalize_kernel: a slot per thread).
 __device__ __forceinline__ void gn_sum_pairs(const float* base, int n, int slot, double& s, double& q) {
   if ((reinterpret_cast<uintptr_t>(base) & 15) == 0 && (n & 1) == 0) {
     const float4* b4 = reinterpret_cast<const float4*>(base);
@@ -232,41 +204,6 @@ __device__ __forceinline__ void gn_sum_pairs(const float* base, int n, int slot,
     }
   } else {
     for (int i = slot; i < n; i += 256) { s += (double)base[2 * i]; q += (double)base[2 * i + 1]; }
-  }
-}
-
-// the slots lane, lane + 64, lane + 128, lane + 192 of the same order in ONE loop (slot k of this lane = accumulator k): every
-// slot still takes its elements in increasing order
-// COH: the pairs are read with device-coherent loads (ConvArgs::fin_mode 1); the additions are the same
-template <bool COH>
-__device__ __forceinline__ void gn_sum_pairs_wave(const float* base, int n, int lane, double (&s)[4], double (&q)[4]) {
-  if ((reinterpret_cast<uintptr_t>(base) & 15) == 0 && (n & 1) == 0) {
-    const float4* b4 = reinterpret_cast<const float4*>(base);
-#pragma unroll 1
-    for (int i0 = lane; i0 < n / 2; i0 += 256) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = i0 + 64 * k;
-        if (i < n / 2) {
-          float4 v;
-          if constexpr (COH) { const float* e = base + 4 * (size_t)i; v = make_float4(drt_load_agent(e), drt_load_agent(e + 1), drt_load_agent(e + 2), drt_load_agent(e + 3)); }
-          else v = b4[i];
-          s[k] += (double)v.x + (double)v.z; q[k] += (double)v.y + (double)v.w;
-        }
-      }
-    }
-  } else {
-#pragma unroll 1
-    for (int i0 = lane; i0 < n; i0 += 256) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = i0 + 64 * k;
-        if (i < n) {
-          const float a = COH ? drt_load_agent(base + 2 * i) : base[2 * i], c = COH ? drt_load_agent(base + 2 * i + 1) : base[2 * i + 1];
-          s[k] += (double)a; q[k] += (double)c;
-        }
-      }
-    }
   }
 }
 
@@ -296,13 +233,12 @@ __device__ __forceinline__ GnGroupSpan gn_group_span(const GnFin& f, int b, int 
 //     |x - mean| <= min(max|x| + |mean|, sqrt(N var))      max|x|: the producers' range bounds amax1 / amax2 (null: unknown)
 //     bound_c = that * rstd * |gamma_c| + |beta_c|,        N var = sum of squared deviations of the group (>= any single one)
 // reduced over the group's channels here and over the groups by an atomic max (order-independent: deterministic).
-template <bool COH = false>
 __device__ __forceinline__ void gn_group_coeffs(const GnFin& f, int b, int g, int lane, double s_tot, double q_tot, int HW) {
   const int C = f.C1 + f.C2, cpg = C / f.G, c_lo = g * cpg;
   float am = -1.f;                    // max |x| of the utterance over both sources; < 0: unknown
   if (f.bound_out && f.amax1 && (f.C2 == 0 || f.amax2)) {        // (whole wave: amax_read shuffles)
-    am = amax_read_t<COH>(f.amax1, b);
-    if (f.C2) am = fmaxf(am, amax_read_t<COH>(f.amax2, b));
+    am = amax_read(f.amax1, b);
+    if (f.C2) am = fmaxf(am, amax_read(f.amax2, b));
   }
   float bnd = 0.f;
   if (lane < cpg) {
@@ -324,45 +260,6 @@ __device__ __forceinline__ void gn_group_coeffs(const GnFin& f, int b, int g, in
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, o));
     if (lane == 0) drt_atomic_max_nonneg(f.bound_out + b * kAmaxSpread + (g & (kAmaxSpread - 1)), bnd);
-  }
-}
-
-// one group by ONE wave: lane l runs the slots l, l + 64, l + 128, l + 192 of the canonical order (one loop, few registers: the
-// tail must stay below the register count of the smallest convolution kernel it is inlined into); the tree's levels 128 and 64
-// are adds inside the lane, the levels 32 ... 1 an xor butterfly (a + b = b + a: every lane ends with the tree's value)
-template <bool COH>
-__device__ __forceinline__ void gn_finalize_group_wave(const GnFin& f, int b, int g, int lane) {
-  const GnGroupSpan sp = gn_group_span(f, b, g);
-  double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
-  if (sp.n1) gn_sum_pairs_wave<COH>(sp.p1, sp.n1, lane, s, q);
-  if (sp.n2) gn_sum_pairs_wave<COH>(sp.p2, sp.n2, lane, s, q);
-  s[0] += s[2]; q[0] += q[2]; s[1] += s[3]; q[1] += q[3];      // m = 128
-  s[0] += s[1]; q[0] += q[1];                                  // m = 64
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { s[0] += drt_shfl_xor_f64(s[0], m); q[0] += drt_shfl_xor_f64(q[0], m); }
-  gn_group_coeffs<COH>(f, b, g, lane, s[0], q[0], sp.HW);
-}
-
-// Tail of a statistics-producing launch (ConvArgs::fin): the last workgroup of utterance b finishes the consumers' GroupNorm
-// coefficients.  Called by the whole workgroup, also by workgroups that have nothing else to do (ragged tiles beyond the
-// utterance's width): they count.  Every launch that reaches this lays its grid out as (tiles of the B utterances, channel
-// blocks): gridDim.x / B * gridDim.y workgroups per utterance.
-__device__ __forceinline__ void conv_gn_tail(const ConvArgs& p, int b) {
-  if (!p.fin) return;                                          // uniform
-  const unsigned per_utt = gridDim.x / (unsigned)p.B * gridDim.y;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (int)(blockDim.x >> 6);
-  if (p.fin_mode == 1) {
-    if (!drt_arrive_last_coherent(p.fin_ctr + b * kAmaxSpread, per_utt)) return;
-    for (int k = 0; k < p.nfin; ++k) {
-      const GnFin f = p.fin[k];
-      for (int g = wave; g < f.G; g += nw) gn_finalize_group_wave<true>(f, b, g, lane);
-    }
-    return;
-  }
-  if (!drt_arrive_last(p.fin_ctr + b * kAmaxSpread, per_utt)) return;
-  for (int k = 0; k < p.nfin; ++k) {
-    const GnFin f = p.fin[k];
-    for (int g = wave; g < f.G; g += nw) gn_finalize_group_wave<false>(f, b, g, lane);
   }
 }
 
@@ -571,12 +468,12 @@ __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&
           st2 = (j & 3) == 0 ? e2 : st2 + e2;
           if (((j & 3) == 3 || (GUARD && y + 1 >= H)) && (!GUARD || co < p.Cout)) {
             float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)(y >> 2) * tiles_x + tx) * 2;
-            if (p.fin_mode == 1) { drt_store_agent(so, st1); drt_store_agent(so + 1, st2); } else { so[0] = st1; so[1] = st2; }
+            so[0] = st1; so[1] = st2;
           }
         } else {
           if (!GUARD || co < p.Cout) {
             float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)y * tiles_x + tx) * 2;
-            if (p.fin_mode == 1) { drt_store_agent(so, e1); drt_store_agent(so + 1, e2); } else { so[0] = e1; so[1] = e2; }
+            so[0] = e1; so[1] = e2;
           }
         }
       }
@@ -618,8 +515,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
 }
 
 // Second half of a split-K convolution: the chunks' partial sums, summed in chunk order into the accumulator layout of the
-// producing tile shape (elements outside the tensor: 0).  Used by conv_splitk_reduce_kernel and by the chunk kernels' own last
-// workgroup (ConvArgs::splitk_ctr).
+// producing tile shape (elements outside the tensor: 0).
 template <class T, int FC, int FP, int WC>
 __device__ __forceinline__ void conv_splitk_sum(const ConvArgs& p, int nchunks, int b, int co_blk, int tx, int ty, int wc, int wp,
                                                 int l31, int kh, f32x16 (&acc)[FC][FP]) {
@@ -685,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
   int b, ty, tx;
   conv_tile_of(p, (int)blockIdx.x, (int)gridDim.x, tiles_xg, tiles_y, b, ty, tx);
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
   const int tiles_x = (p.W + 31) >> 5;
   const int x0 = tx * 32, y0 = ty * ROWS;
   const int co_blk = blockIdx.y;
@@ -938,12 +834,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
       q.out = p.partial + (size_t)blockIdx.z * conv_partial_slab(p, H, W);
       q.bias = nullptr; q.bias2 = nullptr; q.res = nullptr; q.acc_scale = nullptr; q.out_scale = 1.f; q.stats_out = nullptr; q.amax_out = nullptr;
       conv_epilogue<T, FC, FP, WC>(q, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
-      if (!p.splitk_ctr) return;                       // conv_splitk_reduce_kernel follows
-      if (!drt_arrive_last(p.splitk_ctr + blockIdx.y * gridDim.x + blockIdx.x, gridDim.z)) return;
-      conv_splitk_sum<T, FC, FP, WC>(p, (int)gridDim.z, b, co_blk, tx, ty, wc, wp, l31, kh, acc);
-      conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
-      conv_gn_tail(p, b);
-      return;
+      return;                                          // conv_splitk_reduce_kernel follows
     }
   } else {
     load_stage(0);
@@ -958,7 +849,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
   }
 
   conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
-  conv_gn_tail(p, b);
 }
 
 // Second half of a split-K convolution (ConvArgs::kchunk_stages): sums the chunks' partial sums in chunk order into the
@@ -973,7 +863,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
   int b, ty, tx;
   conv_tile_of(p, (int)blockIdx.x, (int)gridDim.x, tiles_xg, tiles_y, b, ty, tx);
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
@@ -985,7 +875,6 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
   float as_mul = 1.0f;
   if (p.xbound) as_mul = 1.0f / h2_weight_scale(amax_read(p.xbound, b));
   conv_epilogue<T, FC, FP, WC, 0, false, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as_mul);
-  conv_gn_tail(p, b);
 }
 
 // Direct (VALU) convolution: one thread per output pixel, CG output channels per thread.

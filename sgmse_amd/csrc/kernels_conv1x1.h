@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs p) {
   const int tiles_y = (p.H + T::ROWS - 1) / T::ROWS;
   int b, ty, tx;
   conv_tile_of(p, (int)blockIdx.x, (int)gridDim.x, tiles_xg, tiles_y, b, ty, tx);
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
@@ -148,7 +148,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs p) {
   }
 
   conv_epilogue<T, FC, FP, 1>(p, acc, b, co_blk, tx, ty, tiles_x, 0, wave, l31, kh);
-  conv_gn_tail(p, b);
 }
 
 }  // namespace sgmse

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs p) {
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
   int b, ty, tx;
   conv_tile_of(p, (int)blockIdx.x, (int)gridDim.x, tiles_xg, tiles_y, b, ty, tx);
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
   const int tiles_x = (p.W + 31) >> 5;
   const int x0 = tx * 32, y0 = ty * ROWS;
   const int co_blk = blockIdx.y;
@@ -228,7 +228,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs p) {
   if (s < nst) stage(B0{}, clampst(s + 1), clampst(s + 2));
 
   conv_epilogue<T, FC, FP, WC>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh);
-  conv_gn_tail(p, b);
 }
 
 }  // namespace sgmse

@@ -190,9 +190,8 @@ inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<
 // the first K-stage (no raw loads, producer, LDS writes), 16 B fragments read from LDS once, 32 A fragments loaded once;
 // correct results: 64 phase time stamps per workgroup (ConvArgs::trace), 128 / 256 epilogue variants (conv_epilogue), 512 LDS
 // padded to one workgroup per CU.
-// BLK: register blocking of a wave inside the 128-channel block: 0 = 1 channel fragment x all pixel fragments (B operand
-// read by all four waves, A operand private), 1 = 2 channel fragments x half of the pixel fragments (half the LDS operand
-// reads; each A fragment loaded by two waves; the two channel fragments' MFMAs alternate, so no MFMA waits on its predecessor).
+// (a 2 x 4 register blocking of a wave -- two channel fragments x half of the pixel fragments, half the LDS operand reads --
+// measured the same as this 1 x 8 blocking, profiles/r02: gpu_r02_blk.sh; removed in round 4)
 // SC = 1: with the folded 1x1 residual shortcut (ConvArgs::sc_*): its K-stages run first on accumulators that start from
 // zero; the accumulators are then rescaled by the (exact, power-of-two) ratio of the two operand scalings, receive the
 // bias terms, and the 3x3 stages continue on top.
@@ -200,14 +199,13 @@ inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<
 // (ConvArgs::kchunk_stages, stages of 16 channels): the K reduction is the sum, in chunk order, of per-chunk partial sums; one
 // workgroup runs all chunks (gridDim.z == 1) or one chunk each (gridDim.z == chunks, raw partial sums to ConvArgs::partial,
 // summed and finished by conv_splitk_reduce_kernel<3, 4, 1, 4>) -- bit-identical.  The bias terms are added by the epilogue.
-template <class S, int SHAPE = 0, int ACT = 1, int ABL = 0, int BLK = 0, int SC = 0, int CHK = 0>
+template <class S, int SHAPE = 0, int ACT = 1, int ABL = 0, int SC = 0, int CHK = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
-  static_assert(!CHK || (SHAPE == 2 && !SC && !BLK), "chunked accumulation exists for the plain 4-row shape");
+  static_assert(!CHK || (SHAPE == 2 && !SC), "chunked accumulation exists for the plain 4-row shape");
   constexpr bool THIN = SHAPE == 1;
   constexpr int ROWS = SHAPE == 2 ? 4 : 8;
   using C = ConvSplitGeom<ROWS>;
-  static_assert(!(THIN && BLK), "the thin shape has one channel fragment");
-  constexpr int WCW = THIN ? 1 : (BLK ? 2 : 4);     // waves along the output channels
+  constexpr int WCW = THIN ? 1 : 4;                 // waves along the output channels
   constexpr int FCW = THIN ? 1 : 4 / WCW;           // channel fragments per wave
   constexpr int FPW = THIN ? 2 : ROWS / (4 / WCW);  // pixel fragments (image rows) per wave
   // epilogue geometry: WCW channel-waves x FCW fragments, 4 / WCW pixel-waves x FPW fragments
@@ -237,20 +235,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       trace[1] = drt_clock();
     }
   }
-  if (p.stagger_units > 0) {          // de-phase the first residency round (ConvArgs::stagger_units)
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-    if (lin < (unsigned)p.stagger_slots) {
-      const unsigned h = (lin * 2654435761u) >> 28;                                       // 0..15, scattered
-      const unsigned ph = p.stagger_mode == 0 ? h : ((lin / ((unsigned)p.stagger_slots / 2)) & 1u) * 8u + (h >> 1);
-      for (unsigned i = 0; i < ph * (unsigned)p.stagger_units; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
   const int Cin = p.C1 + p.C2;
   const int tiles_xg = (p.W + 31) >> 5;       // grid layout (ragged launches: of the widest utterance)
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
   int b, ty, tx;
   conv_tile_of(p, (int)blockIdx.x, (int)gridDim.x, tiles_xg, tiles_y, b, ty, tx);
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) { if (gridDim.z == 1 || (p.splitk_ctr && blockIdx.z == 0)) conv_gn_tail(p, b); return; } }
+  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
   const int co_blk = blockIdx.y;
@@ -630,8 +620,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       if (st + 1 < nst) thin_stage(st + 1, s_in1, s_in0, rin2);
     }
     conv_epilogue<T, FCW, FPW, WCW, 0, true, false>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
-    conv_gn_tail(p, b);
-    return;
+      return;
   }
   constexpr int AR = 3, AD = AR - 1;
   u32x4 ar[AR][FCW][NS];
@@ -698,9 +687,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       q.out = p.partial + (size_t)blockIdx.z * conv_partial_slab(p, H, W);
       q.bias = nullptr; q.bias2 = nullptr; q.res = nullptr; q.acc_scale = nullptr; q.out_scale = 1.f; q.stats_out = nullptr; q.amax_out = nullptr;
       conv_epilogue<T, FCW, FPW, WCW, 0, true>(q, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg);
-      // (conv_splitk_reduce_kernel follows.  The in-launch reduce of the fp32 kernels, ConvArgs::splitk_ctr, is not built into
-      // this kernel: with the chunk sums' 64 extra registers it spilled -- 217 -> 256 VGPRs + 37 spilled -- for a mechanism that
-      // measured slower anyway, profiles/r03_arrive_last_ab.txt)
+      // (conv_splitk_reduce_kernel follows)
       return;
     }
   }
@@ -713,7 +700,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
 
   if constexpr (ABL & 64) { if (trace) trace[3] = drt_clock(); }
   conv_epilogue<T, FCW, FPW, WCW, ABL & (3 | 128 | 256), !CHK, FPW % 4 == 0>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
-  conv_gn_tail(p, b);
   if constexpr (ABL & 64) { if (trace) trace[4] = drt_clock(); }
 }
 

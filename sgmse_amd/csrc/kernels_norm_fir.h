@@ -57,9 +57,7 @@ __global__ __launch_bounds__(256) void gn_chan_stats_kernel(const float* src1, c
 // of statistics sub-tiles when a convolution epilogue produced them); the two sources of a virtual concat may differ.
 // grid = (G, B): one workgroup per group.  The partials of a group's channels are contiguous per source, so the 256 threads
 // stream them coalesced (the canonical slot order and fp64 tree of gn_sum_pairs, kernels_conv.h: deterministic), then lane c < cpg
-// of wave 0 writes the folded coefficients of channel g*cpg + c.  The same job runs, with the same additions in the same order,
-// in the tail of the producing convolution when the engine asks for that (conv_gn_tail): this kernel is the path of the tensors
-// whose partials are too many for one workgroup per utterance, or that no convolution epilogue produced.
+// of wave 0 writes the folded coefficients of channel g*cpg + c.
 // Ragged launch (rag.w): utterance b has H * rag.w[b] pixels per plane; a source whose partials come from a convolution
 // epilogue (nsub > 1) holds them packed per utterance -- (H / rps) * ceil(w / 32) sub-tiles per channel from sub-tile rag.soff[b] / rps on,
 // exactly the layout of the utterance's own launch; gn_chan_stats sources (nsub == 1) are one pair per (b, c) either way.

@@ -65,43 +65,6 @@ __device__ __forceinline__ void drt_atomic_max_nonneg(float* p, float v) {
   atomicMax(reinterpret_cast<unsigned int*>(p), __builtin_bit_cast(unsigned int, v));
 }
 
-// Arrival counter of a last-workgroup reduction.  Called by the WHOLE workgroup once its results are stored: every wave releases
-// its global stores at device scope, the arrival is counted, and the return value is true -- for every thread -- in the workgroup
-// that arrives last, after an acquire: its loads then see what all the other workgroups stored before they arrived.  Which
-// workgroup that is differs from run to run; what it computes must not (fixed summation order in the caller).
-// The two halves are separate fences on purpose.  On this part every XCD has its own L2: a device-scope RELEASE writes the L2's
-// dirty lines back (buffer_wbl2), a device-scope ACQUIRE invalidates it (buffer_inv) -- and an invalidation makes every other
-// workgroup of the XCD fetch its weights again.  With a full fence (__threadfence) in every arriving workgroup a launch of the
-// coarse levels took 25-100 us longer (profiles/r03_arrive_last_ab.txt); only the last workgroup needs the acquire.
-__device__ __forceinline__ bool drt_arrive_last(unsigned* ctr, unsigned expected) {
-  __shared__ unsigned s_arrive_last;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();
-  if (threadIdx.x == 0) s_arrive_last = (__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1u) ? 1u : 0u;
-  __syncthreads();
-  const bool last = s_arrive_last != 0u;
-  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return last;
-}
-// The same arrival WITHOUT cache maintenance, for data that is itself accessed coherently: the producers write it with
-// drt_store_agent (device-scope relaxed atomic store: `global_store ... sc1`, written through), the last workgroup reads it with
-// drt_load_agent (`global_load ... sc1`), the counter is a relaxed device-scope read-modify-write.  Ordering comes from the
-// instruction stream, not from the memory model: every wave waits for its stores to complete (s_waitcnt vmcnt(0)) before the
-// workgroup barrier that precedes the count, and the last workgroup issues its loads after the barrier that follows it.  No
-// buffer_wbl2, no buffer_inv.  Experimental (SGMSE_GN_TAIL_MODE=1): relies on a completed sc1 store being visible to sc1 loads of
-// other XCDs, which the bitwise GPU test checks but no specification available here states.
-__device__ __forceinline__ void drt_store_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float drt_load_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool drt_arrive_last_coherent(unsigned* ctr, unsigned expected) {
-  __shared__ unsigned s_arrive_last_c;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) s_arrive_last_c = (__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1u) ? 1u : 0u;
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  return s_arrive_last_c != 0u;
-}
 // xor-shuffle of a double (two 32-bit shuffles)
 __device__ __forceinline__ double drt_shfl_xor_f64(double v, int mask) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -137,6 +100,16 @@ __device__ __forceinline__ float drt_xadd(float a, float b) {
   }
 }
 __device__ __forceinline__ float drt_add_xor2(float a) { return drt_dpp_add<0x4E>(a); }
+// whole-wave shifts by one lane (DPP wave_shr:1 / wave_shl:1, one v_mov_b32_dpp each, no LDS-pipe traffic): drt_wave_shr1(v) = the
+// value of lane - 1 (lane 0: 0), drt_wave_shl1(v) = the value of lane + 1 (lane 63: 0).  All lanes must be active.
+__device__ __forceinline__ float drt_wave_shr1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float drt_wave_shl1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+// a value every lane of the wave agrees on (the wave index), moved to a scalar register so that branches on it stay scalar
+__device__ __forceinline__ int drt_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // execution barrier among the lanes of one wave around wave-private LDS traffic: the hardware runs a wave in lock step and
 // executes its LDS operations in order, so this only pins the compiler's ordering (the emulator synchronises its fibers)

@@ -19,6 +19,8 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct float2 { float x, y; };
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 struct alignas(16) float4 { float x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
@@ -90,6 +92,18 @@ static inline float drt_xadd(float a, float b) {
   return (lane & bit) ? b + bp : a + ap;
 }
 static inline float drt_add_xor2(float a) { return a + emu::shfl_xor(a, 2); }
+// whole-wave shifts by one lane (see sgmse_amd/csrc/sgmse_devrt.h): lane - 1 / lane + 1, zero at the wave's ends
+static inline float drt_wave_shr1(float v) {
+  const int lane = (int)(threadIdx.x & 63);
+  const float t = emu::shfl_idx(v, lane > 0 ? lane - 1 : lane);
+  return lane > 0 ? t : 0.f;
+}
+static inline float drt_wave_shl1(float v) {
+  const int lane = (int)(threadIdx.x & 63);
+  const float t = emu::shfl_idx(v, lane < 63 ? lane + 1 : lane);
+  return lane < 63 ? t : 0.f;
+}
+static inline int drt_uniform(int v) { return v; }
 static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) { return emu::mfma_16x16x4(a, b, c); }
 #define __builtin_amdgcn_iglp_opt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
@@ -112,20 +126,6 @@ static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __A
 
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-// arrival counter of a last-workgroup reduction (see sgmse_amd/csrc/sgmse_devrt.h); workgroups run on a pool of OS threads here
-static inline bool drt_arrive_last(unsigned* ctr, unsigned expected) {
-  __shared__ unsigned s_arrive_last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_arrive_last = (atomicAdd(ctr, 1u) == expected - 1u) ? 1u : 0u;
-  __syncthreads();
-  const bool last = s_arrive_last != 0u;
-  if (last) __threadfence();
-  return last;
-}
-static inline void drt_store_agent(float* p, float v) { *p = v; }
-static inline float drt_load_agent(const float* p) { return *p; }
-static inline bool drt_arrive_last_coherent(unsigned* ctr, unsigned expected) { return drt_arrive_last(ctr, expected); }
 static inline double drt_shfl_xor_f64(double v, int mask) {
   uint64_t u; memcpy(&u, &v, 8);
   uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);

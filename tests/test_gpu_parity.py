@@ -58,6 +58,20 @@ def test_conv_direct(hip, shape):
     P.check_conv(hip, *shape, direct=True)
 
 
+def test_conv3x3_winograd_fp16x2_kernel_has_fp32_accuracy(hip):
+    """Winograd F(2,3) x fp16x2 (kernels_conv_wino.h) on the hardware: the whole-wave DPP shifts of the input transform, 512-thread
+    workgroups with 132 KB of LDS, the 4-row shape bit-equal to the 8-row shape, per-channel weight scales."""
+    P.check_conv_wino(hip, 1, 32, 128, 9, 34)
+    P.check_conv_wino(hip, 2, 48, 128, 8, 32, xmul=50.0)
+    P.check_conv_wino(hip, 1, 64, 256, 5, 40, dual=32)
+    P.check_conv_wino(hip, 1, 16, 128, 12, 64, xform=False, res=False)
+    P.check_conv_wino(hip, 1, 32, 128, 8, 32, wmul=6)
+    P.check_conv_wino(hip, 2, 128, 128, 64, 96)
+    P.check_conv_wino(hip, 1, 384, 128, 32, 64, dual=128)
+    P.check_conv_wino(hip, 1, 512, 256, 16, 32, dual=256)
+    P.check_conv_wino(hip, 2, 256, 256, 64, 128, wmul=4)
+
+
 def test_conv3x3_bf16x3_kernel_has_fp32_accuracy(hip):
     P.check_conv_b3(hip, 1, 32, 128, 9, 33)
     P.check_conv_b3(hip, 2, 48, 128, 8, 32, xform=True)
@@ -466,15 +480,8 @@ def test_split_k_of_the_coarse_levels_never_changes_a_bit(hip):
 
 @pytest.mark.parametrize("name", ["fwd_nf32", "fwd_nf128"])
 def test_xcd_aware_tile_order_never_changes_a_bit(hip, name):
-    """SGMSE_CONV_XCD_MAP=1 (off by default, to be measured): a permutation of the tile -> workgroup assignment of the convolutions"""
+    """SGMSE_CONV_XCD_MAP (on since round 4, profiles/r04_knobs_ab.txt): a permutation of the tile -> workgroup assignment of the convolutions"""
     P.check_xcd_map_bitwise(hip, name)
-
-
-@pytest.mark.parametrize("name", ["fwd_nf32", "fwd_nf128"])
-def test_groupnorm_coefficients_in_the_convolution_tail_never_change_a_bit(hip, name):
-    """GroupNorm coefficients finished by the last workgroup of each utterance in the producing launch (device-scope release /
-    acquire around an arrival counter) vs gn_finalize_kernel launches: bit-identical network output, batch of fixtures."""
-    P.check_gn_tail_bitwise(hip, name)
 
 
 @pytest.mark.parametrize("every_layer_split", [False, True])
@@ -492,11 +499,11 @@ def test_ragged_batch_gives_every_utterance_its_single_run_bits(hip):
     P.check_ragged_batch(hip, "fwd_nf128", frames=(512, 64, 192, 320, 128))
 
 
-@pytest.mark.skipif(not os.environ.get("SGMSE_TEST_EXPERIMENTAL"), reason="built after the round's GPU time was spent: run with SGMSE_TEST_EXPERIMENTAL=1")
-def test_ragged_launches_over_the_tiles_that_exist_give_the_same_bits(hip, monkeypatch):
-    """SGMSE_RAGGED_PREFIX=1 + SGMSE_CONV_XCD_MAP=1 at full width (see the emulator test of the same name)"""
-    monkeypatch.setenv("SGMSE_RAGGED_PREFIX", "1")
-    monkeypatch.setenv("SGMSE_CONV_XCD_MAP", "1")
+def test_ragged_launches_over_the_widest_utterances_grid_give_the_same_bits(hip, monkeypatch):
+    """the layout that was the default until round 4 (grid over the widest utterance's tile columns, plain tile order): the default
+    since -- launches over the tiles that exist, XCD-aware tile order -- is what every other ragged test runs"""
+    monkeypatch.setenv("SGMSE_RAGGED_PREFIX", "0")
+    monkeypatch.setenv("SGMSE_CONV_XCD_MAP", "0")
     P.check_ragged_batch(hip, "fwd_nf128", frames=(512, 64, 192, 320, 128))
 
 

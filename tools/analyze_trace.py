@@ -19,7 +19,9 @@ print(f"{len(a)} workgroups; kernel span {t[:, 3].max()} cycles")
 for name, v in (("prologue", pro), ("K loop", loop), ("epilogue", epi), ("total", t[:, 3] - t[:, 0])):
     print(f"{name:9s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}  p90 {np.percentile(v, 90):9.0f}")
 ts = a[:, 5:15].astype(np.int64)
-if ts.sum() > 0:
+if len(sys.argv) > 2 and sys.argv[2] == "wino":      # conv3x3_wino_kernel<..., TRACE>: [5] = LDS exchange, [6] = time at the stage barriers
+    print(f"output-transform exchange mean {ts[:, 0].mean():9.0f}; stage barriers (thread 0) mean {ts[:, 1].mean():9.0f} cycles")
+elif ts.sum() > 0:
     tot = ts.sum(axis=1).mean()
     print("K loop of wave 0, mean time per tap position summed over the stages (share of the loop):")
     for i in range(9):

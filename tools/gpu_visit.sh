@@ -1,0 +1,109 @@
+#!/bin/bash
+# One parameterised GPU visit (replaces the per-visit scripts of rounds 2-3).  Runs on the gpurun box from the repo root:
+#   gpurun --timeout 900 -- 'STEPS=pytest,bench TAG=r04 bash tools/gpu_visit.sh'
+# STEPS (comma list, run in this order):
+#   smoke      __graft_entry__.smoke()
+#   pytest     pytest -m gpu (PYTEST_K = -k expression, PYTEST_X=1 stops at the first failure)
+#   micro      tools/conv_microbench.py (VARIANTS / SHAPES / FUSED / ROUNDS as that script reads them)
+#   trace      phase time stamps of a traced kernel instantiation (TRACE_VARIANTS, TRACE_SHAPE) through tools/analyze_trace.py
+#   power      tools/power_probe.py (CASES, ITERS)
+#   ab         bench.py A/B: AB = ';'-separated "name|bench args|ENV=1 ENV2=0" entries
+#   bench      bench.py with the driver's defaults -> ${TAG}_bench_b32.json
+#   rocprof    rocprofv3 --kernel-trace --stats of the bench command -> ${TAG}_bench_b32_kernel_stats.csv
+#   pmc        PMC passes of the dominant kernel's micro-benchmark (tools/conv_microbench.py) -> ${TAG}_pmc_*.json, ${TAG}_hbm_traffic_*.json
+#   dumps      per-launch timings of one evaluation at batch 32 and batch 1
+#   ragged     tools/ragged_bench.py
+#   dirjob     tools/dir_job_bench.py
+#   lengths    bench.py --seconds sweep (utterance lengths off the 512-frame grid)
+# Everything lands in gpurun_out/ with the TAG prefix; copy what is to be judged into profiles/.
+set +e
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+O=gpurun_out
+TAG=${TAG:-r04}
+STEPS=${STEPS:-smoke,pytest,bench}
+has() { [[ ",$STEPS," == *",$1,"* ]]; }
+val() { python -c "
+import json
+d=json.loads(open('$1').read().strip().splitlines()[-1]); k=(d.get('kernel_classes_one_eval') or {}).get('conv3x3_wide') or {}
+print('$2', round(d['value'],4), d.get('unit','utt/s'), round(d['ms_per_step'],1), 'ms/step; dominant class', k.get('ms'), 'ms', k.get('tflops'), 'TFLOP/s; frac', (d.get('roofline') or {}).get('frac'), 'power', (d.get('power') or {}).get('mean_w'))" 2>/dev/null || echo "$2 FAILED"; }
+rocm-smi --showproductname 2>/dev/null | head -8 > $O/gpu.txt; nproc >> $O/gpu.txt
+if has smoke; then echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -2 | tee $O/${TAG}_smoke.txt; fi
+if has pytest; then
+  echo "== pytest -m gpu ${PYTEST_K:+-k \"$PYTEST_K\"}"
+  timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q -s -p no:cacheprovider ${PYTEST_X:+-x} ${PYTEST_K:+-k "$PYTEST_K"} > $O/${TAG}_pytest_gpu${PYTEST_NAME:+_$PYTEST_NAME}.log 2>&1
+  echo "pytest rc=$?"; tail -3 $O/${TAG}_pytest_gpu${PYTEST_NAME:+_$PYTEST_NAME}.log | cut -c1-300
+  grep -E "^(FAILED|ERROR)|Memory access|Error" $O/${TAG}_pytest_gpu${PYTEST_NAME:+_$PYTEST_NAME}.log | head -20
+  grep -E "^conv_wino|^conv_split" $O/${TAG}_pytest_gpu${PYTEST_NAME:+_$PYTEST_NAME}.log | head -30
+fi
+if has micro; then
+  echo "== kernel micro-benchmark (VARIANTS=$VARIANTS SHAPES=$SHAPES FUSED=$FUSED)"
+  OUT=${TAG}_conv_microbench.json timeout 600 python tools/conv_microbench.py 2>&1 | grep -v amdgpu | tee $O/${TAG}_conv_microbench.txt
+fi
+if has trace; then
+  # phase time stamps of the traced kernel instantiations (bench_conv variant bit 18 = ablation 64): TRACE_VARIANTS, TRACE_SHAPE = "B Cin Cout H W"
+  for v in ${TRACE_VARIANTS:-$((1152 + (64 << 12)))}; do
+    echo "== phase trace, variant $v, shape ${TRACE_SHAPE:-8 128 128 256 512}"
+    SGMSE_TRACE_OUT=$O/trace_$v.bin timeout 120 python -c "
+import sys; sys.path.insert(0, '.')
+from sgmse_amd import _lib
+_lib.load_library(); ctx = _lib.Context('cuda')
+B, ci, co, H, W = map(int, '${TRACE_SHAPE:-8 128 128 256 512}'.split())
+print('ms per launch', ctx.bench_conv(3, B, ci, co, H, W, variant=$v, iters=3, fused=True))" 2>&1 | grep -v amdgpu
+    python tools/analyze_trace.py $O/trace_$v.bin ${TRACE_KIND:-wino} 2>&1 | tee $O/${TAG}_trace_$v.txt | head -${TRACE_LINES:-30}
+    rm -f $O/trace_$v.bin
+  done
+fi
+if has power; then
+  echo "== power probe (CASES=$CASES)"
+  timeout 600 python tools/power_probe.py 2>&1 | grep -v amdgpu | tee $O/${TAG}_power_probe.txt | cut -c1-400
+fi
+if has ab; then
+  echo "== bench A/B"
+  : > $O/${TAG}_ab.txt
+  IFS=';' read -ra ENTRIES <<< "$AB"
+  for ent in "${ENTRIES[@]}"; do
+    IFS='|' read -r name args envs <<< "$ent"
+    env $envs timeout 400 python bench.py $args > $O/ab_$name.json 2>$O/ab_$name.err
+    val $O/ab_$name.json "$name [$envs] [$args]" | tee -a $O/${TAG}_ab.txt
+  done
+fi
+if has bench; then echo "== bench (driver defaults)"; timeout 900 python bench.py > $O/${TAG}_bench_b32.json 2>$O/${TAG}_bench.err; echo "bench rc=$?"; cut -c1-900 $O/${TAG}_bench_b32.json; tail -2 $O/${TAG}_bench.err; fi
+if has rocprof; then
+  echo "== rocprofv3 kernel trace of the bench command"
+  rm -rf $O/prof
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-others > $O/${TAG}_prof_bench.log 2>$O/${TAG}_prof.err; echo "rocprof rc=$?"
+  f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_bench_b32_kernel_stats.csv && head -8 "$f" | cut -c1-200
+  rm -rf $O/prof
+fi
+if has pmc; then
+  # counters of the dominant kernel on its micro-benchmark, one pass per counter group (the guide's HBM recipe: FETCH_SIZE and
+  # WRITE_SIZE in separate passes, calibrated on a float4 stream of known size in the same run)
+  echo "== PMC passes (PMC_VARIANT=${PMC_VARIANT:-1152})"
+  for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+    n=$(echo $grp | tr ' ' '_' | cut -c1-40)
+    rm -rf $O/pmc_$n
+    VARIANTS=${PMC_VARIANT:-1152} SHAPES=${PMC_SHAPES:-0} FUSED=1 ROUNDS=1 CALIB=1 OUT=${TAG}_pmc_microbench.json timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_$n -o pmc -- python tools/conv_microbench.py > $O/pmc_$n.log 2>&1
+    echo "pmc [$grp] rc=$?"
+  done
+  python tools/summarize_pmc.py $O ${TAG} 2>&1 | tail -30
+fi
+if has dumps; then
+  echo "== per-launch timings of one evaluation (batch 32 and batch 1)"
+  for b in ${DUMP_BATCHES:-32 1}; do
+    SGMSE_PROFILE_DUMP=1 timeout 300 python bench.py --batch $b --N 2 --steps 1 --warmup 1 --no-cpu-baseline --no-others > /dev/null 2> $O/${TAG}_prof_dump_b${b}.txt
+    grep -c sgmse-prof $O/${TAG}_prof_dump_b${b}.txt
+  done
+fi
+if has ragged; then echo "== ragged bench"; timeout 600 python tools/ragged_bench.py --profile > $O/${TAG}_ragged_bench.txt 2>&1; tail -4 $O/${TAG}_ragged_bench.txt | cut -c1-1200; fi
+if has dirjob; then echo "== directory job"; timeout 600 python tools/dir_job_bench.py > $O/${TAG}_dir_job.txt 2>&1; tail -5 $O/${TAG}_dir_job.txt | cut -c1-500; fi
+if has lengths; then
+  echo "== utterance lengths"
+  : > $O/${TAG}_length_sweep.txt
+  for s in ${LENGTHS:-3.0 3.5 4.0 4.5 5.0}; do
+    timeout 300 python bench.py --seconds $s --steps 2 --warmup 1 --no-others --no-cpu-baseline > $O/len_$s.json 2>/dev/null
+    val $O/len_$s.json "seconds=$s" | tee -a $O/${TAG}_length_sweep.txt
+  done
+fi
+echo "== done"

@@ -31,13 +31,16 @@ def sample(stop, out):
         time.sleep(0.15)
 
 
-for name, variant in (("fp16x2 split kernel (full)", 128), ("fp16x2 MFMA-only loop, no epilogue memory (ablation 59)", 128 + (59 << 12)),
-                      ("fp16x2 no staging (ablation 8)", 128 + (8 << 12)), ("fp32 MFMA kernel", 0)):
+CASES = {"split": ("fp16x2 split kernel (full)", 128), "mfma_only": ("fp16x2 MFMA-only loop, no epilogue memory (ablation 59)", 128 + (59 << 12)),
+         "no_staging": ("fp16x2 no staging (ablation 8)", 128 + (8 << 12)), "fp32": ("fp32 MFMA kernel", 0),
+         "wino": ("Winograd F(2,3) x fp16x2 kernel", 128 + 1024)}
+ITERS = int(os.environ.get("ITERS", "3500"))
+for name, variant in (CASES[k] for k in os.environ.get("CASES", "split,mfma_only,no_staging,fp32").split(",")):
     ctx.bench_conv(3, 8, 128, 128, 256, 512, variant=variant, iters=20, fused=True)      # warm
     stop, log = threading.Event(), []
     th = threading.Thread(target=sample, args=(stop, log)); th.start()
     t0 = time.time()
-    ms = ctx.bench_conv(3, 8, 128, 128, 256, 512, variant=variant, iters=3500, fused=True)
+    ms = ctx.bench_conv(3, 8, 128, 128, 256, 512, variant=variant, iters=ITERS, fused=True)
     dt = time.time() - t0
     stop.set(); th.join()
     mid = [(p, c) for (t, p, c) in log if t0 + 0.4 < t < t0 + dt - 0.1 and p is not None]
