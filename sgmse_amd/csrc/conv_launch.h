@@ -156,8 +156,14 @@ inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t
 inline bool conv_wino_eligible(int C1, int C2, int Cout, int W) {
   return Cout % 128 == 0 && (C1 + C2) % 16 == 0 && (C2 == 0 || C1 % 16 == 0) && (C1 + C2) <= 512 && W % 2 == 0;
 }
-inline void launch_conv_wino(const ConvArgs& a, drt::stream_t st, bool rows4, bool trace = false) {
+inline void launch_conv_wino(const ConvArgs& a, drt::stream_t st, bool rows4, bool trace = false, int abl = 0) {
   const bool act = a.in_scale && a.in_act;
+#ifdef SGMSE_ABLATION_FULL
+#define SGMSE_WABL_CASE(V) if (abl == V) { DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0, 0, V>), dim3(conv_grid_tiles(a, 8), a.Cout / 128, 1), dim3(512), st, a); return; }
+  SGMSE_WABL_CASE(1) SGMSE_WABL_CASE(2) SGMSE_WABL_CASE(4) SGMSE_WABL_CASE(8) SGMSE_WABL_CASE(16) SGMSE_WABL_CASE(24) SGMSE_WABL_CASE(3) SGMSE_WABL_CASE(32) SGMSE_WABL_CASE(20)
+#undef SGMSE_WABL_CASE
+#endif
+  (void)abl;
   if (trace) { DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0, 1>), dim3(conv_grid_tiles(a, 8), a.Cout / 128, 1), dim3(512), st, a); return; }
   if (rows4) {
     const dim3 grid(conv_grid_tiles(a, 4), a.Cout / 128, 1);

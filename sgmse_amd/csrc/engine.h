@@ -727,12 +727,12 @@ class Engine {
     unsigned long long* trace_dev = nullptr;
     const size_t n_wg = (size_t)B * ((H + 7) / 8) * ((W + 31) / 32) * ((Cout + 127) / 128);
     if (abl_split & 64) {
-      trace_dev = static_cast<unsigned long long*>(dev_alloc_tmp(n_wg * 128));
-      SG_CHECK(drt::memset_dev(trace_dev, 0, n_wg * 128, stream_));
+      trace_dev = static_cast<unsigned long long*>(dev_alloc_tmp(n_wg * 256));      // (16 words per workgroup; the Winograd kernel's trace: 32)
+      SG_CHECK(drt::memset_dev(trace_dev, 0, n_wg * 256, stream_));
       a.trace = trace_dev;
     }
     auto go = [&]() {
-      if (wino) launch_conv_wino(a, stream_, split_rows4, (abl_split & 64) != 0);
+      if (wino) launch_conv_wino(a, stream_, split_rows4, (abl_split & 64) != 0, abl_split & 63);
       else if (b3) launch_conv_split(a, ks, smode, stream_, split_rows4, abl_split);
       else launch_conv_mfma(a, ks, pl, stream_, variant);
     };
@@ -745,8 +745,9 @@ class Engine {
     check_launch();
     drt::event_destroy(&e0); drt::event_destroy(&e1);
     if (trace_dev) {                    // phase time stamps of the LAST launch -> $SGMSE_TRACE_OUT (binary: 16 x u64 per workgroup)
-      std::vector<unsigned long long> h(n_wg * 16);
-      SG_CHECK(drt::memcpy_d2h(h.data(), trace_dev, n_wg * 128, stream_));
+      const size_t words = wino ? 32 : 16;
+      std::vector<unsigned long long> h(n_wg * words);
+      SG_CHECK(drt::memcpy_d2h(h.data(), trace_dev, n_wg * words * 8, stream_));
       SG_CHECK(drt::stream_sync(stream_));
       if (const char* path = getenv("SGMSE_TRACE_OUT")) { if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); } }
       free_tmp(trace_dev);

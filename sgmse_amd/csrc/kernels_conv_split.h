@@ -95,8 +95,7 @@ struct SplitH2 {
   // two consecutive K-elements -> {hi pair, lo pair}: two packed round-to-nearest conversions (v_cvt_pk_f16_f32)
   __device__ static __forceinline__ void split2(float x0, float x1, uint32_t (&d)[2]) {
     const uint32_t hi = drt_f32x2_to_f16x2(x0, x1);
-    const float r0 = x0 - drt_f16_to_f32(hi & 0xffffu), r1 = x1 - drt_f16_to_f32(hi >> 16);
-    d[0] = hi; d[1] = drt_f32x2_to_f16x2(r0, r1);
+    d[0] = hi; d[1] = drt_f32x2_to_f16x2(drt_sub_f16_lo(x0, hi), drt_sub_f16_hi(x1, hi));      // four instructions per pair
   }
   __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) { return mfma_32x32x16_f16(a, b, c); }
 };

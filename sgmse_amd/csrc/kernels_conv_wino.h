@@ -52,9 +52,10 @@ struct WinoGeom {
   static constexpr int NSROW = 4 * TROWS;             // staging rows: (4-channel group q, tile row r), q fastest
   static constexpr int NPASS = (NSROW + 2) / 3;       // wave passes of 3 staging rows x 18 lanes
   static constexpr int NIT = (NPASS + 7) / 8;         // passes per wave
-  static constexpr int XS = ROWS_ * 32 + 8;           // floats per output channel in the exchange buffer (+8: kg halves 32 banks apart)
   static constexpr int CO_V = 512;                    // producer coefficient table, u32x4 per input channel
-  static constexpr int LDS_V = (2 * STAGE_V + CO_V) > (128 * XS / 4) ? (2 * STAGE_V + CO_V) : (128 * XS / 4);
+  static constexpr int NDIR = ROWS_ == 4 ? 1 : 2;     // epilogue exchange: B-waves -> A-waves only (4 rows), or both ways
+  static constexpr int XCH_V = 4 * NDIR * 2 * 16 * 64 / 2;   // ... [channel fragment][direction][fragment slot][register][lane] float2, in u32x4
+  static constexpr int LDS_V = (2 * STAGE_V + CO_V) > XCH_V ? (2 * STAGE_V + CO_V) : XCH_V;
 };
 template <int ROWS_>
 struct WinoTile { static constexpr int CO_T = 128, ROWS = ROWS_; };
@@ -124,7 +125,9 @@ __global__ __launch_bounds__(256) void pack_weights_wino_kernel(PackWinoArgs p, 
 // SC = 1: with the folded 1x1 residual shortcut (ConvArgs::sc_*, as conv3x3_split_kernel): its K-stages run first into M0 (even
 // columns) and M3 (odd columns, negated), the accumulators are rescaled to the 3x3 stages' operand scaling and the stages continue.
 // TRACE (measurement only, sgmse_bench_conv): phase time stamps per workgroup (ConvArgs::trace; tools/analyze_trace.py).
-template <int ROWS, int ACT, int SC, int TRACE = 0>
+// ABL (measurement only, `make ABLATION=1`; results WRONG on purpose): 1 producer without the transcendental pair, 2 input transform without the
+// cross-lane shifts, 4 no LDS writes of the staged tile, 8 no staging at all behind the prologue, 16 no raw loads in the K loop, 32 the split arithmetic without its LDS stores.
+template <int ROWS, int ACT, int SC, int TRACE = 0, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   using G = WinoGeom<ROWS>;
   using T = WinoTile<ROWS>;
@@ -134,7 +137,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   u32x4* const s_in0 = s_all;
   u32x4* const s_in1 = s_all + G::STAGE_V;
   f32x4* const s_co = reinterpret_cast<f32x4*>(s_all + 2 * G::STAGE_V);
-  float* const s_x = reinterpret_cast<float*>(s_all);       // exchange buffer of the epilogue (the stage buffers are dead by then)
 
   const int tid = threadIdx.x;
   const int wave = drt_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   unsigned long long* trace = nullptr;
   if constexpr (TRACE) {
     if (tid == 0 && p.trace) {
-      trace = p.trace + 16 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+      trace = p.trace + 32 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
       trace[0] = (unsigned long long)drt_hw_id() | ((unsigned long long)drt_xcc_id() << 32);
       trace[1] = drt_clock();
     }
@@ -206,36 +208,41 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
       rin[i][2 * c] = v.x; rin[i][2 * c + 1] = v.y;
     }
   };
-  auto produce = [&](float x, int ch, bool ok) -> float {
-    const f32x4 co = s_co[ch];
+  // input transform of one channel of an item: V[k] from this lane's pair (e, o), the odd column of lane - 1 and the even column of lane + 1
+  float V[4][4];
+  // producer of one element from a prefetched coefficient vector {s kx, h kx, s (-log2 e), h (-log2 e)}
+  auto produce_co = [&](float x, const f32x4& co, bool ok) -> float {
     float o = x * co[0] + co[1];
     if constexpr (ACT == 1) {
       const float u = x * co[2] + co[3];
-      o = o * __builtin_amdgcn_rcpf(1.0f + drt_exp2(u));       // SiLU: t * sigmoid(t), exponent pre-multiplied by -log2 e
+      if constexpr (ABL & 1) o = o * u; else o = o * __builtin_amdgcn_rcpf(1.0f + drt_exp2(u));
     }
-    o = fminf(fmaxf(o, -32752.f), 32752.f);                    // (cannot bind: the scaled bound is < 2^14; keeps |V| finite in fp16)
-    return ok ? o : 0.f;                                       // zero padding applies to the producer's OUTPUT
+    return ok ? o : 0.f;
   };
-  // input transform of one channel of an item: V[k] from this lane's pair (e, o), the odd column of lane - 1 and the even column of lane + 1
-  float V[4][4];
-  auto stage_chan = [&](int i, int c, int c0) {
-    const int ch = c0 + 4 * it_q[i] + c;
-    const float e = produce(rin[i][2 * c], ch, it_ok[i]), o = produce(rin[i][2 * c + 1], ch, it_ok[i]);
-    const float ol = drt_wave_shr1(o), er = drt_wave_shl1(e);
+  auto stage_chan_co = [&](int i, int c, const f32x4& co) {
+    const float e = produce_co(rin[i][2 * c], co, it_ok[i]), o = produce_co(rin[i][2 * c + 1], co, it_ok[i]);
+    const float ol = (ABL & 2) ? e : drt_wave_shr1(o), er = (ABL & 2) ? o : drt_wave_shl1(e);
     V[0][c] = ol - o; V[1][c] = e + o; V[2][c] = o - e; V[3][c] = e - er;
   };
-  auto flush_item = [&](int i, u32x4* sbuf) {
-    if (it_wr[i]) {
+  auto stage_chan = [&](int i, int c, int c0) { stage_chan_co(i, c, s_co[c0 + 4 * it_q[i] + c]); };
+  // split + LDS write of component k of an item (4 channels: two packed pairs per split term)
+  auto flush_k = [&](int i, int k, u32x4* sbuf) {
+    if (it_wr[i] && (!(ABL & 4) || V[k][0] == 12345.678f)) {
       uint2* w = reinterpret_cast<uint2*>(sbuf) + it_woff[i];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        uint32_t d01[2], d23[2];
-        S::split2(V[k][0], V[k][1], d01);
-        S::split2(V[k][2], V[k][3], d23);
+      uint32_t d01[2], d23[2];
+      S::split2(V[k][0], V[k][1], d01);
+      S::split2(V[k][2], V[k][3], d23);
+      if constexpr (ABL & 32) {               // the split arithmetic without the stores
+        if ((d01[0] ^ d23[1]) == 0x12345678u) w[k * 8] = make_uint2(d01[0] ^ d01[1], d23[0] ^ d23[1]);
+      } else {
         w[k * 8] = make_uint2(d01[0], d23[0]);          // (k: 4 u32x4 = 8 halves; split: 1 u32x4 = 2 halves)
         w[k * 8 + 2] = make_uint2(d01[1], d23[1]);
       }
     }
+  };
+  auto flush_item = [&](int i, u32x4* sbuf) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) flush_k(i, k, sbuf);
   };
 
   const int nst = Cin / G::KC;
@@ -305,9 +312,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   // one tap = component k of kernel row dy: NF position fragments x 3 split products; behind each fragment's MFMAs a share of the
   // staging work of `item` (the next stage's tile): the four channel transforms spread over the fragments, the LDS writes last
   u32x4 bq[2][NS];
-  auto compute_tap = [&](const u32x4* sbuf, int tap, int kq, const u32x4 (&a)[NS], int item, int c0n, u32x4* nxt) {
+  auto compute_tap = [&](const u32x4* sbuf, int tap, int kq, const u32x4 (&a)[NS], int item, bool stage_here, int c0n, u32x4* nxt) {
     const int dy = tap >> 1, kk = tap & 1;
     const u32x4* sb = sbuf + b_lane + dy * G::ROW_V + kq * 4;
+    // the item's four coefficient vectors first: a read issued right in front of its use waits out the whole LDS queue (eight waves'
+    // operand reads) -- four exposed round trips per item were ~60 % of a staging tap (profiles/r04_wino_trace.txt)
+    f32x4 co4[4];
+    if (item >= 0 && stage_here) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) co4[c] = s_co[c0n + 4 * it_q[item] + c];
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) bq[0][s] = sb[s];
 #pragma unroll
@@ -320,10 +334,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
       __builtin_amdgcn_sched_barrier(SGMSE_SPLIT_FENCE);
 #pragma unroll
       for (int k = 0; k < S::NP; ++k) acc[kk][f] = S::mfma(a[S::pa(k)], bq[f & 1][S::pb(k)], acc[kk][f]);
-      if (item >= 0) {
+      if (item >= 0 && stage_here) {
         constexpr int CPF = 4 / NF;                   // channels per fragment slot (1 for 8 rows, 2 for 4)
 #pragma unroll
-        for (int c = 0; c < CPF; ++c) stage_chan(item, f * CPF + c, c0n);
+        for (int c = 0; c < CPF; ++c) stage_chan_co(item, f * CPF + c, co4[f * CPF + c]);
         if (f == NF - 1) flush_item(item, nxt);
       }
       __builtin_amdgcn_sched_barrier(SGMSE_SPLIT_FENCE);
@@ -344,57 +358,82 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
     const bool s_ok = s_live && sgy < H && sgx < W;
     const unsigned s_boff = ((unsigned)(4 * sq) * HW + (s_ok ? (unsigned)(sgy * W + sgx) : 0u)) * 4u;
     const int s_woff = (((sr + 1) * 16 + sjm) * PV + (sq >> 1) * NS) * 2 + (sq & 1);      // tile row sr + 1 (the centre tap reads dy = 1)
-    float rsa[8], rsb[8];
-    auto load_sc = [&](int c0, float (&dst)[8]) {
-      const bool first = c0 < p.sc_C1;
-      const float* base = first ? p.sc_src1 + ((size_t)b * p.sc_C1 + c0) * HW : p.sc_src2 + ((size_t)b * p.sc_C2 + (c0 - p.sc_C1)) * HW;
+    // Two 16-channel stages per barrier ("super-stage"): the centre tap uses one component slot per wave group, so the first stage of
+    // a pair goes to the slots k = 0 (even columns, A-waves) / k = 3 (negated odd columns, B-waves) of the tile buffer and the second
+    // to k = 1 / k = 2 -- 24 MFMAs per wave between barriers instead of 12.  Raw inputs and
+    // weight fragments one super-stage ahead (a fragment loaded right in front of its MFMAs exposed an L2 round trip per stage; two
+    // register sets for two super-stages of cover spilled).
+    const int nss = (nsts + 1) / 2;
+    float rsa[16];
+    auto load_sc = [&](int ss, float (&dst)[16]) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base + (size_t)c * HW) + s_boff);
-        dst[2 * c] = v.x; dst[2 * c + 1] = v.y;
+      for (int h = 0; h < 2; ++h) {
+        const int st = 2 * ss + h < nsts ? 2 * ss + h : nsts - 1;      // (odd stage count: the last half is loaded twice, stored and used once)
+        const int c0 = st * G::KC;
+        const bool first = c0 < p.sc_C1;
+        const float* base = first ? p.sc_src1 + ((size_t)b * p.sc_C1 + c0) * HW : p.sc_src2 + ((size_t)b * p.sc_C2 + (c0 - p.sc_C1)) * HW;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base + (size_t)c * HW) + s_boff);
+          dst[8 * h + 2 * c] = v.x; dst[8 * h + 2 * c + 1] = v.y;
+        }
       }
     };
-    auto store_sc = [&](const float (&src)[8], u32x4* sbuf) {
+    auto store_sc = [&](const float (&src)[16], u32x4* sbuf, int ss) {
       if (!s_live) return;
-      float ev[4], od[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        ev[c] = s_ok ? fminf(fmaxf(src[2 * c] * xs, -65504.f), 65504.f) : 0.f;
-        od[c] = s_ok ? -fminf(fmaxf(src[2 * c + 1] * xs, -65504.f), 65504.f) : 0.f;
-      }
       uint2* w = reinterpret_cast<uint2*>(sbuf) + s_woff;
-      uint32_t d01[2], d23[2];
-      S::split2(ev[0], ev[1], d01); S::split2(ev[2], ev[3], d23);
-      w[0] = make_uint2(d01[0], d23[0]); w[2] = make_uint2(d01[1], d23[1]);                 // k = 0
-      S::split2(od[0], od[1], d01); S::split2(od[2], od[3], d23);
-      w[3 * 8] = make_uint2(d01[0], d23[0]); w[3 * 8 + 2] = make_uint2(d01[1], d23[1]);     // k = 3
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 && 2 * ss + 1 >= nsts) break;
+        float ev[4], od[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          ev[c] = s_ok ? src[8 * h + 2 * c] * xs : 0.f;
+          od[c] = s_ok ? -(src[8 * h + 2 * c + 1] * xs) : 0.f;
+        }
+        uint32_t d01[2], d23[2];
+        const int ke = h, ko = 3 - h;                 // component slots of the even / odd columns of this half
+        S::split2(ev[0], ev[1], d01); S::split2(ev[2], ev[3], d23);
+        w[ke * 8] = make_uint2(d01[0], d23[0]); w[ke * 8 + 2] = make_uint2(d01[1], d23[1]);
+        S::split2(od[0], od[1], d01); S::split2(od[2], od[3], d23);
+        w[ko * 8] = make_uint2(d01[0], d23[0]); w[ko * 8 + 2] = make_uint2(d01[1], d23[1]);
+      }
     };
     const u32x4* wsc = reinterpret_cast<const u32x4*>(p.sc_w) + (size_t)co_blk * nsts * NS * 4 * 64;
-    auto load_asc = [&](int st, u32x4 (&a)[NS]) {
-      const u32x4* q = wsc + (size_t)st * NS * 4 * 64;
+    auto load_asc = [&](int ss, u32x4 (&a)[2][NS]) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s * 4 * 64) + a_boff);
-    };
-    load_sc(0, rsa);
-    load_sc((nsts > 1 ? 1 : 0) * G::KC, rsb);
-    store_sc(rsa, s_in0);
-    __syncthreads();
-    u32x4 asc[NS];
-    // tap index 2 + kh: kernel row 1, accumulator set kh (M0 in the A-waves, M3 in the B-waves); component slot 3 kh in LDS
-#pragma unroll 1
-    for (int st = 0; st < nsts; st += 2) {
-      load_asc(st, asc);
-      if (st + 2 < nsts) load_sc((st + 2) * G::KC, rsa);
-      if (kh == 0) compute_tap(s_in0, 2, 0, asc, -1, 0, s_in1); else compute_tap(s_in0, 3, 3, asc, -1, 0, s_in1);     // (accumulator set by a constant index)
-      if (st + 1 < nsts) store_sc(rsb, s_in1);
-      __syncthreads();
-      if (st + 1 < nsts) {
-        load_asc(st + 1, asc);
-        if (st + 3 < nsts) load_sc((st + 3) * G::KC, rsb);
-        if (kh == 0) compute_tap(s_in1, 2, 0, asc, -1, 0, s_in0); else compute_tap(s_in1, 3, 3, asc, -1, 0, s_in0);
-        if (st + 2 < nsts) store_sc(rsa, s_in0);
-        __syncthreads();
+      for (int h = 0; h < 2; ++h) {
+        const int st = 2 * ss + h < nsts ? 2 * ss + h : nsts - 1;
+        const u32x4* q = wsc + (size_t)st * NS * 4 * 64;
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) a[h][s2] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s2 * 4 * 64) + a_boff);
       }
+    };
+    // kernel row 1 (taps 2, 3); A-waves: accumulator set 0 (M0), slots 0 then 1; B-waves: set 1 (M3), slots 3 then 2
+    auto compute_sc = [&](const u32x4* sbuf, const u32x4 (&a)[2][NS], int ss) {
+      const bool two = 2 * ss + 1 < nsts;
+      if (kh == 0) { compute_tap(sbuf, 2, 0, a[0], -1, false, 0, nullptr); if (two) compute_tap(sbuf, 2, 1, a[1], -1, false, 0, nullptr); }
+      else { compute_tap(sbuf, 3, 3, a[0], -1, false, 0, nullptr); if (two) compute_tap(sbuf, 3, 2, a[1], -1, false, 0, nullptr); }
+    };
+    u32x4 asc[2][NS];
+    load_sc(0, rsa);
+    load_asc(0, asc);
+    store_sc(rsa, s_in0, 0);
+    if (nss > 1) load_sc(1, rsa);
+    __syncthreads();
+    // super-stage ss: MFMAs from buffer ss & 1, then -- behind them -- the weight fragments of ss + 1, the split of ss + 1 (its raw
+    // inputs are in registers) into the other buffer, and the raw loads of ss + 2 into the registers that just became free
+#pragma unroll 1
+    for (int ss = 0; ss < nss; ++ss) {
+      const u32x4* cur = (ss & 1) ? s_in1 : s_in0;
+      u32x4* nxt = (ss & 1) ? s_in0 : s_in1;
+      compute_sc(cur, asc, ss);
+      if (ss + 1 < nss) {
+        load_asc(ss + 1, asc);
+        store_sc(rsa, nxt, ss + 1);
+        if (ss + 2 < nss) load_sc(ss + 2, rsa);
+      }
+      __syncthreads();
     }
     // from the shortcut's operand scaling (weights 2^k1 per layer, input xs) to the 3x3 stages' (weights per channel, input kx), plus
     // the additive terms; M3 holds the NEGATED shortcut, so its terms are negated too
@@ -438,7 +477,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   u32x4 ar[AR][NS];
 #pragma unroll
   for (int t = 0; t < AD; ++t) load_a(0, t, ar[t]);
-  unsigned long long tbar = 0;
+  unsigned long long tbar = 0, ttap[NTAP] = {0, 0, 0, 0, 0, 0};
+  const bool tracer = TRACE && p.trace && (tid == 0 || tid == 256);       // one lane of an A-wave and of a B-wave time their taps
 #pragma unroll 1
   for (int st = 0; st < nst; ++st) {
     const int stn = st + 1 < nst ? st + 1 : st;       // the last stage re-stages itself into the buffer nobody reads again
@@ -447,14 +487,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
     u32x4* nxt = (st & 1) ? s_in0 : s_in1;
 #pragma unroll
     for (int tap = 0; tap < NTAP; ++tap) {
+      unsigned long long tc0 = 0;
+      if constexpr (TRACE) tc0 = drt_clock();
       const int ntap = (tap + AD) % NTAP;
       const int nstg = tap + AD < NTAP ? st : stn;
       load_a(nstg, ntap, ar[(tap + AD) % AR]);        // issued before the raw loads below: vmcnt retires in order
       __builtin_amdgcn_sched_barrier(0);
-      int item = tap - (NTAP - NIT);                  // the last NIT taps carry the staging of items 0 .. NIT - 1
-      if (item >= 0 && !it_run[item]) item = -1;
-      compute_tap(cur, tap, 2 * kh + (tap & 1), ar[tap % AR], item < 0 ? -1 : item, stn * G::KC, nxt);
-      if (item >= 0) load_item(item, stl * G::KC);
+      // staging of the next stage's items: the A-waves in the FIRST NIT taps, the B-waves in the LAST -- the two waves of a SIMD are
+      // (cf, kh = 0) and (cf, kh = 1), and in lock step they would run their VALU-heavy taps together and then compete for the matrix
+      // pipe together; de-phased, one wave's producer arithmetic issues beside the other's MFMAs.  (Measured alternatives, all slower:
+      // B-waves in taps 2-3, +2-3 %; the staging cut into 16 units spread one per fragment slot over the stage, +5 %.)
+      // (one call with a uniform predicate around the staging pieces only: two calls under a branch put every accumulator in a phi)
+      constexpr int BT0 = NTAP - NIT;
+      const bool ca = tap < NIT, cb = tap >= BT0 && tap < BT0 + NIT;   // (constants once the tap loop is unrolled)
+      const int item = ca ? tap : cb ? tap - BT0 : -1;
+      const bool stage_here = !(ABL & 8) && item >= 0 && it_run[item < 0 ? 0 : item] && (ca ? kh == 0 : kh == 1);
+      compute_tap(cur, tap, 2 * kh + (tap & 1), ar[tap % AR], item, stage_here, stn * G::KC, nxt);
+      if constexpr (!(ABL & 16)) { if (stage_here) load_item(item < 0 ? 0 : item, stl * G::KC); }
+      if constexpr (TRACE) { __builtin_amdgcn_sched_barrier(0); ttap[tap] += drt_clock() - tc0; }
     }
     if constexpr (TRACE) {
       const unsigned long long tb = drt_clock();
@@ -464,53 +514,152 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
       __syncthreads();
     }
   }
-  if constexpr (TRACE) { if (trace) { trace[3] = drt_clock(); trace[6] = tbar; } }
+  if constexpr (TRACE) {
+    if (trace) { trace[3] = drt_clock(); trace[6] = tbar; }
+    if (tracer) {
+      unsigned long long* tq = p.trace + 32 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x) + (tid == 0 ? 16 : 23);
+#pragma unroll
+      for (int i = 0; i < NTAP; ++i) tq[i] = ttap[i];
+      tq[6] = tbar;
+    }
+  }
 
-  // ---- output transform through LDS: [co 128][row][col] fp32, XS floats per channel ------------------------------------------
+  // ---- output transform + epilogue in the accumulators' own (position) layout -----------------------------------------------------
+  // A-waves hold {a0, a1} = {M0 + M1, M1}, B-waves {b0, b1} = {M2, M2 + M3}; y(2m) = a0 + b0, y(2m+1) = a1 - b1.  The partners swap
+  // HALF of their partial sums through LDS (one barrier): the A-wave of a channel fragment finishes the fragments of rows 0-3, the
+  // B-wave those of rows 4-7 (4-row shape: the A-wave takes everything) -- each wave ends with 32 channels x 4 rows x 32 columns, a
+  // lane holding the column pair (2m, 2m+1) of row 2f + (l31 >> 4): 8-byte residual loads and output stores (16 lanes = one 128-byte
+  // row segment), GroupNorm partials of the 4-row sub-tile by ONE 32-lane butterfly per wave, no second pass through LDS.
   // (the loop's last barrier has passed: nobody reads the stage buffers any more)
+  constexpr int EF = 2;                                   // fragments (row pairs) a wave finishes
+  constexpr bool ALL_TO_A = ROWS == 4;
+  const bool fin_wave = !ALL_TO_A || kh == 0;
+  const int ef0 = ALL_TO_A ? 0 : 2 * kh;                   // first fragment this wave finishes
+  const int pos_row = l31 >> 4, m2 = 2 * (l31 & 15);
+  const int yb = y0 + 2 * ef0 + pos_row, x = x0 + m2;      // row of fragment slot 0, first column of the pair
+  const bool okc = x < W;
+  const bool inside = x0 + 32 <= W && y0 + ROWS <= H;      // workgroup-uniform: no access of the tile needs a guard
+  const size_t ubase = (size_t)b * p.Cout * HW;
+  const int co_l = co_blk * 128 + cf * 32 + 4 * kg;        // + (r & 3) + 8 (r >> 2)
+  // byte offset of fragment slot f of this lane inside the utterance (clamped into the image: guarded accesses never use the value)
+  unsigned lane_boff[EF];
+#pragma unroll
+  for (int f = 0; f < EF; ++f) {
+    const int yy = yb + 2 * f < H ? yb + 2 * f : H - 1;
+    lane_boff[f] = (((unsigned)co_l * (unsigned)H + (unsigned)yy) * (unsigned)W + (unsigned)(okc ? x : 0)) * 4u;
+  }
+  auto soff = [&](int r) -> unsigned { return (unsigned)((r & 3) + 8 * (r >> 2)) * HW * 4u; };
+  const drt_buf obuf = drt_make_buf(p.out + ubase), rbuf = drt_make_buf(p.res ? p.res + ubase : p.out);
+  // residual rows first: their HBM latency passes behind the exchange.  Unpredicated (clamped addresses): a predicated load
+  // compiles to a branch and a full vmcnt wait each
+  const bool has_res = !SC && p.res != nullptr;          // (a folded shortcut replaces the residual: ConvArgs::sc_*)
+  float2 rr[SC ? 1 : EF][SC ? 1 : 16];
+  if constexpr (!SC) {
+    if (fin_wave && has_res) {
+#pragma unroll
+      for (int f = 0; f < EF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rr[f][r] = drt_buf_load2(rbuf, lane_boff[f], soff(r));
+    }
+  }
+  if constexpr (TRACE) { if (trace) trace[7] = drt_clock() - trace[3]; }       // residual loads issued
   {
-    const int pos_row = l31 >> 4, m2 = 2 * (l31 & 15);
-    float* xw = s_x + (cf * 32 + 4 * kg) * G::XS + pos_row * 32 + m2;
+    // exchange slots: [channel fragment][direction: 0 = for the A-wave, 1 = for the B-wave][fragment slot][register][lane] float2
+    float2* xs = reinterpret_cast<float2*>(s_all);
+    auto slot = [&](int dir, int f, int r) -> float2* { return xs + ((((cf * G::NDIR + dir) * EF + f) * 16 + r) * 64 + lane); };
+    if (kh == 0) {
+      if constexpr (!ALL_TO_A) {
+#pragma unroll
+        for (int f = 0; f < EF; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float a1 = acc[1][EF + f][r]; *slot(1, f, r) = make_float2(acc[0][EF + f][r] + a1, a1); }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < EF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float b0 = acc[0][f][r]; *slot(0, f, r) = make_float2(b0, b0 + acc[1][f][r]); }
+    }
+    if constexpr (TRACE) { if (trace) trace[8] = drt_clock() - trace[3]; }     // partial sums written
+    __syncthreads();
+    if constexpr (TRACE) { if (trace) trace[9] = drt_clock() - trace[3]; }     // barrier passed
+    if (!fin_wave) return;
     if (kh == 0) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f)
+      for (int f = 0; f < EF; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          const float2 bb = *slot(0, f, r);
           const float a1 = acc[1][f][r], a0 = acc[0][f][r] + a1;
-          *reinterpret_cast<float2*>(xw + ((r & 3) + 8 * (r >> 2)) * G::XS + f * 64) = make_float2(a0, a1);
+          acc[0][f][r] = a0 + bb.x; acc[1][f][r] = a1 - bb.y;
         }
-    }
-    __syncthreads();
-    if (kh == 1) {
+    } else {
+      if constexpr (!ALL_TO_A) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f)
+        for (int f = 0; f < EF; ++f)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float b0 = acc[0][f][r], b1 = b0 + acc[1][f][r];
-          float2* q = reinterpret_cast<float2*>(xw + ((r & 3) + 8 * (r >> 2)) * G::XS + f * 64);
-          const float2 v = *q;
-          *q = make_float2(v.x + b0, v.y - b1);
-        }
+          for (int r = 0; r < 16; ++r) {
+            const float2 aa = *slot(1, f, r);
+            const float b0 = acc[0][EF + f][r], b1 = b0 + acc[1][EF + f][r];
+            acc[0][f][r] = aa.x + b0; acc[1][f][r] = aa.y - b1;       // (into the slots 0 .. EF - 1: the loop below reads those)
+          }
+      }
     }
-    __syncthreads();
   }
   if constexpr (TRACE) { if (trace) trace[5] = drt_clock() - trace[3]; }
-  // every wave takes 32 channels x 4 rows in the shared epilogue's layout (lane = column); ROWS = 4: the A-waves only
-  constexpr int FP = 4;
-  if (ROWS == 4 && kh == 1) return;
-  f32x16 out[1][FP];
-  {
+  auto finish = [&](auto guard_tag) {
+    constexpr bool GUARD = decltype(guard_tag)::value;
     float cs_inv[16];
     load_cs(cs_inv);
-    const float* xr = s_x + (cf * 32 + 4 * kg) * G::XS + (ROWS == 8 ? kh * 4 : 0) * 32 + l31;
+    float s1[16], s2[16], vmax = 0.f;
 #pragma unroll
-    for (int j = 0; j < FP; ++j)
+    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) out[0][j][r] = xr[((r & 3) + 8 * (r >> 2)) * G::XS + j * 32] * cs_inv[r];
-  }
-  ConvArgs q = p;
-  q.acc_scale = nullptr;
-  conv_epilogue<T, 1, FP, 4, 0, true, true>(q, out, b, co_blk, tx, ty, tiles_x, cf, ROWS == 8 ? kh : 0, l31, kg, inv_kx);
+    for (int f = 0; f < EF; ++f) {
+      const bool ok = !GUARD || (okc && yb + 2 * f < H);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v0 = acc[0][f][r] * cs_inv[r] * inv_kx, v1 = acc[1][f][r] * cs_inv[r] * inv_kx;      // exact powers of two
+        if constexpr (!SC) { if (has_res) { v0 += rr[f][r].x; v1 += rr[f][r].y; } }
+        v0 *= p.out_scale; v1 *= p.out_scale;
+        if (ok) drt_buf_store2(obuf, make_float2(v0, v1), lane_boff[f], soff(r));
+        if (GUARD) { v0 = ok ? v0 : 0.f; v1 = ok ? v1 : 0.f; }
+        vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
+        s1[r] = (s1[r] + v0) + v1;
+        s2[r] = (s2[r] + v0 * v0) + v1 * v1;
+      }
+      DRT_PIN_HERE(vmax);
+    }
+    if constexpr (TRACE) { if (trace) trace[10] = drt_clock() - trace[3]; }    // outputs stored (issued)
+    if (p.stats_out && y0 + 2 * ef0 < H) {
+      // {sum, sum of squares} of the wave's 4-row x 32-column sub-tile per channel: the 16 per-lane sums of each kind through one
+      // exchange-add butterfly over the 32 lanes of a half wave (as conv_epilogue, once per wave instead of once per row)
+      auto butterfly = [&](float (&sv)[16]) -> float {
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = drt_xadd<16>(sv[k], sv[k + 8]);
+        float c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = drt_xadd<8>(a[k], a[k + 4]);
+        const float d0 = drt_xadd<7>(c[0], c[2]), d1 = drt_xadd<7>(c[1], c[3]);
+        return drt_add_xor2(drt_xadd<1>(d0, d1));
+      };
+      const float e2 = butterfly(s2);
+      __builtin_amdgcn_sched_barrier(0);
+      const float e1 = butterfly(s1);
+      const int r = ((l31 >> 4) & 1) * 8 + ((l31 >> 3) & 1) * 4 + ((l31 >> 2) & 1) * 2 + (l31 & 1);
+      const int co = co_l + (r & 3) + 8 * (r >> 2);
+      float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)((y0 + 2 * ef0) >> 2) * tiles_x + tx) * 2;
+      so[0] = e1; so[1] = e2;
+    }
+    if (p.amax_out) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+      if (lane == 0) drt_atomic_max_nonneg(p.amax_out + b * kAmaxSpread + ((blockIdx.x * 8 + wave) & (kAmaxSpread - 1)), vmax);
+    }
+    DRT_CODE_MARKER(GUARD);
+  };
+  if (inside) finish(std::false_type{}); else finish(std::true_type{});
   if constexpr (TRACE) { if (trace) trace[4] = drt_clock(); }
 }
 

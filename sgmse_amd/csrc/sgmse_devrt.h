@@ -36,6 +36,10 @@ __device__ __forceinline__ uint32_t drt_f32x2_to_f16x2(float x0, float x1) {
   const f2_t v = {x0, x1};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2_t));
 }
+// x - (float)(half `hi_sel` of the packed fp16 pair h), one rounding: v_fma_mix_f32 (an fp32 fma that reads an operand as fp16) -- one
+// instruction where a conversion and a subtraction would be two; bit-identical to them (the product h * -1 is exact)
+__device__ __forceinline__ float drt_sub_f16_lo(float x, uint32_t h) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
+__device__ __forceinline__ float drt_sub_f16_hi(float x, uint32_t h) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
 // IEEE single multiply / add that the compiler must not contract into a fused multiply-add (where a reference's rounding
 // sequence has to be reproduced operation by operation)
 __device__ __forceinline__ float drt_mul_rn(float a, float b) { return __fmul_rn(a, b); }
@@ -55,6 +59,18 @@ __device__ __forceinline__ float drt_buf_load(const drt_buf& b, unsigned voff, u
 template <int AUX = 0>
 __device__ __forceinline__ void drt_buf_store(const drt_buf& b, float v, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, voff, soff, AUX);
+}
+// the same for two consecutive floats (8-byte aligned): buffer_load/store_dwordx2
+template <int AUX = 0>
+__device__ __forceinline__ float2 drt_buf_load2(const drt_buf& b, unsigned voff, unsigned soff) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, AUX);
+  return make_float2(__builtin_bit_cast(float, (unsigned)v[0]), __builtin_bit_cast(float, (unsigned)v[1]));
+}
+template <int AUX = 0>
+__device__ __forceinline__ void drt_buf_store2(const drt_buf& b, float2 v, unsigned voff, unsigned soff) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  const u2_t u = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)};
+  __builtin_amdgcn_raw_buffer_store_b64(u, b.r, voff, soff, AUX);
 }
 // measurement: shader clock and the hardware placement of this wave (HW_REG_HW_ID, HW_REG_XCC_ID)
 __device__ __forceinline__ unsigned long long drt_clock() { return __builtin_amdgcn_s_memtime(); }

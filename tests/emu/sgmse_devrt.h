@@ -70,10 +70,16 @@ template <int AUX = 0>
 static inline float drt_buf_load(const drt_buf& b, unsigned voff, unsigned soff) { float v; memcpy(&v, b.p + voff + soff, 4); return v; }
 template <int AUX = 0>
 static inline void drt_buf_store(const drt_buf& b, float v, unsigned voff, unsigned soff) { memcpy(b.p + voff + soff, &v, 4); }
+template <int AUX = 0>
+static inline float2 drt_buf_load2(const drt_buf& b, unsigned voff, unsigned soff) { float2 v; memcpy(&v, b.p + voff + soff, 8); return v; }
+template <int AUX = 0>
+static inline void drt_buf_store2(const drt_buf& b, float2 v, unsigned voff, unsigned soff) { memcpy(b.p + voff + soff, &v, 8); }
 static inline unsigned long long drt_clock() { return 0; }
 static inline unsigned drt_hw_id() { return 0; }
 static inline unsigned drt_xcc_id() { return 0; }
 static inline uint32_t drt_f32x2_to_f16x2(float x0, float x1) { return emu::f32_to_f16(x0) | (emu::f32_to_f16(x1) << 16); }
+static inline float drt_sub_f16_lo(float x, uint32_t h) { volatile float r = x - emu::f16_to_f32(h & 0xffffu); return r; }
+static inline float drt_sub_f16_hi(float x, uint32_t h) { volatile float r = x - emu::f16_to_f32(h >> 16); return r; }
 static inline float drt_exp2(float x) { return exp2f(x); }
 static inline float drt_mul_rn(float a, float b) { volatile float r = a * b; return r; }     // (volatile: no contraction whatever the flags)
 static inline float drt_add_rn(float a, float b) { volatile float r = a + b; return r; }

@@ -6,7 +6,8 @@ import sys
 
 import numpy as np
 
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16)
+WINO = len(sys.argv) > 2 and sys.argv[2] == "wino"
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 32 if WINO else 16)
 a = a[a[:, 1] > 0]
 hw = (a[:, 0] & np.uint64(0xffffffff)).astype(np.int64)
 xcc = (a[:, 0] >> np.uint64(32)).astype(np.int64) & 0xf
@@ -21,6 +22,12 @@ for name, v in (("prologue", pro), ("K loop", loop), ("epilogue", epi), ("total"
 ts = a[:, 5:15].astype(np.int64)
 if len(sys.argv) > 2 and sys.argv[2] == "wino":      # conv3x3_wino_kernel<..., TRACE>: [5] = LDS exchange, [6] = time at the stage barriers
     print(f"output-transform exchange mean {ts[:, 0].mean():9.0f}; stage barriers (thread 0) mean {ts[:, 1].mean():9.0f} cycles")
+    print("epilogue of wave 0, cycles from the end of the K loop: residual loads issued %.0f, partial sums written %.0f, barrier passed %.0f, "
+          "combined %.0f, outputs stored %.0f, end %.0f" % (ts[:, 2].mean(), ts[:, 3].mean(), ts[:, 4].mean(), ts[:, 0].mean(), ts[:, 5].mean(), epi.mean()))
+    for name, off in (("A-wave (thread 0)", 16), ("B-wave (thread 256)", 23)):
+        tt = a[:, off:off + 7].astype(np.int64)
+        print(f"K loop of the {name}: cycles per tap position summed over the stages " + " ".join(f"{tt[:, i].mean():.0f}" for i in range(6)) +
+              f"; at the stage barriers {tt[:, 6].mean():.0f}")
 elif ts.sum() > 0:
     tot = ts.sum(axis=1).mean()
     print("K loop of wave 0, mean time per tap position summed over the stages (share of the loop):")

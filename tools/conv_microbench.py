@@ -25,7 +25,7 @@ ALL_SHAPES = [  # ks, B, Cin, Cout, H, W
 SHAPES = [ALL_SHAPES[int(i)] for i in os.environ.get("SHAPES", "0,1,2,3").split(",")]
 FUSED = [int(v) for v in os.environ.get("FUSED", "0,1").split(",")]
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
-_lib.load_library()
+_lib.load_library(os.environ.get("SGMSE_LIB_PATH"))      # (measurement: an alternative build of the library)
 ctx = _lib.Context("cuda")
 res = {}
 for (ks, B, ci, co, H, W) in SHAPES:

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import torch
 from sgmse_amd import _lib
 
-_lib.load_library()
+_lib.load_library(os.environ.get("SGMSE_LIB_PATH"))      # (measurement: an alternative build of the library)
 ctx = _lib.Context("cuda")
 
 
