@@ -13,6 +13,7 @@ only stores the outputs: the sampled spectrogram [1,1,F,T] complex64 and the enh
   ode16k_full  configs[2]:     same network and utterance, fixed-step probability-flow Euler N=30              (30 NFE)
   pc48k_full   configs[3]:     ncsnpp_48k, F=768, T=128 (0.96 s @48 kHz, reflection pad), PC N=50 snr=0.33     (100 NFE)
   pc48k_T512   configs[3] at the benched shape: F=768, T=512 (4 s @48 kHz), PC N=5 snr=0.33                   (10 NFE)
+  pc48k_T512_N50  configs[3] as benched: the same utterance with N=50                                          (100 NFE)
 
 The oracle restatement runs beside the reference on the same inputs and its deviation goes into
 tests/golden/REPORT_full.txt (this is the oracle's pin at full configuration).

@@ -820,14 +820,21 @@ class Engine {
     SG_CHECK(drt::stream_sync(stream_));
     SG_CHECK(drt::graph_begin_capture(stream_));
     capturing_ = true;
-    try { body(); } catch (...) { capturing_ = false; throw; }
+    try { body(); } catch (...) {
+      // leave the stream usable: end the capture, throw its graph away, and forget the executable a stale update would have reused
+      capturing_ = false;
+      drt::graph_abort_capture(stream_);
+      drop_graph();
+      throw;
+    }
     capturing_ = false;
     if (graph_stale_) {
       const int r = drt::graph_end_capture_update(stream_, &graph_);
-      if (r > 0) { graph_stale_ = false; SG_CHECK(r); }
+      if (r > 0) { drt::graph_destroy(&graph_); graph_stale_ = false; graph_valid_ = false; SG_CHECK(r); }     // (nothing left to leak or to reuse)
       if (r == 0) ++graph_updates_; else ++graph_captures_;
     } else {
-      SG_CHECK(drt::graph_end_capture(stream_, &graph_));
+      const int r = drt::graph_end_capture(stream_, &graph_);
+      if (r != 0) { drt::graph_destroy(&graph_); graph_valid_ = false; SG_CHECK(r); }
       ++graph_captures_;
     }
     graph_stale_ = false;

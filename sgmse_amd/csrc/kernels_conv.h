@@ -251,7 +251,9 @@ __device__ __forceinline__ void gn_group_coeffs(const GnFin& f, int b, int g, in
     const float a = f.gamma[c] * rstd;
     f.scale[(size_t)b * C + c] = a;
     f.shift[(size_t)b * C + c] = f.beta[c] - (float)mean * a;
-    double dev = sqrt(n * var);
+    // (q / n - mean^2 comes from fp32 partial sums: for |mean| >> std the cancellation can under-estimate n var by ~2^-21 n mean^2 --
+    //  that much is added back, so the bound stays a bound; negligible next to n var whenever var is not itself lost in the rounding)
+    double dev = sqrt(n * var + n * mean * mean * 9.5367431640625e-07);
     if (am >= 0.f) dev = fmin(dev, (double)am + fabs(mean));
     bnd = (float)(dev * (double)rstd * fabs((double)f.gamma[c]) + fabs((double)f.beta[c])) * 1.0001f;   // (margin for the fp32 affine's own rounding)
     if (!(bnd >= 0.f)) bnd = 3.0e38f;      // NaN statistics: the result is NaN whatever the scale

@@ -190,6 +190,13 @@ inline int graph_end_capture_update(stream_t st, graph_t* g) {
   e = hipGraphInstantiate(&g->x, g->g, nullptr, nullptr, 0);
   return e == hipSuccess ? -1 : int(e);      // -1: worked, but as a new instantiation
 }
+// a capture that must not produce a graph (its body failed): end it and discard whatever was recorded
+inline void graph_abort_capture(stream_t st) {
+  hipGraph_t g = nullptr;
+  (void)hipStreamEndCapture(st, &g);
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+}
 inline int graph_launch(graph_t* g, stream_t st) { return int(hipGraphLaunch(g->x, st)); }
 inline int graph_destroy(graph_t* g) {
   if (g->x) (void)hipGraphExecDestroy(g->x);

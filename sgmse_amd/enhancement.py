@@ -224,6 +224,8 @@ class _Writer:
             job = self.q.get()
             if job is None:
                 return
+            if self.err is not None:
+                continue                # after the first failure: drain the queue without writing (put() raises on the main thread)
             try:
                 event, items = job
                 if event is not None:
@@ -231,7 +233,7 @@ class _Writer:
                 for host, peak, out_path, sr in items:
                     write_audio(out_path, host.numpy() * peak, sr)                 # renormalise (enhancement.py:102)
                     self.done += 1
-            except Exception as e:      # noqa: BLE001 -- re-raised on the main thread by close()
+            except Exception as e:      # noqa: BLE001 -- re-raised on the main thread by put() / close()
                 self.err = e
 
     def put(self, event, items):
@@ -239,10 +241,10 @@ class _Writer:
             raise self.err
         self.q.put((event, items))
 
-    def close(self) -> int:
+    def close(self, reraise: bool = True) -> int:
         self.q.put(None)
         self.th.join()
-        if self.err is not None:
+        if reraise and self.err is not None:
             raise self.err
         return self.done
 
@@ -334,10 +336,13 @@ def enhance_files(model: ScoreModel, files: List[str], test_dir: str, enhanced_d
                     event = torch.cuda.Event()
                     event.record(torch.cuda.current_stream(device))
                 writer.put(event, items)
-    finally:
+    except BaseException:
+        # an exception of the main loop is the one to report: the writer's own stored error (if any) must not replace it
         pool.shutdown(wait=False, cancel_futures=True)
-        done = writer.close()
-    return done
+        writer.close(reraise=False)
+        raise
+    pool.shutdown(wait=False, cancel_futures=True)
+    return writer.close()
 
 
 def load_model(ckpt: str, device, rank: int, world: int) -> ScoreModel:

@@ -27,11 +27,12 @@ def flatten_state(state: Dict[str, torch.Tensor], device) -> Tuple[torch.Tensor,
     return flat, meta
 
 
-def broadcast_backbone_weights(dnn: torch.nn.Module, src: int = 0):
+def broadcast_backbone_weights(dnn: torch.nn.Module, src: int = 0, force: bool = False):
     """One broadcast of all backbone parameters (65.6 M fp32 = 262 MB for ncsnpp) from ``src``; afterwards every
-    rank's HIP engine is loaded from the received device buffer.  No-op without an initialised process group."""
+    rank's HIP engine is loaded from the received device buffer.  No-op without an initialised process group or with a
+    single rank, unless ``force`` (the single-GPU test of the RCCL path runs the collective at world size 1)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return
     params = dict(dnn.state_dict())
     dev = next(iter(params.values())).device

@@ -177,6 +177,7 @@ inline bool graphs_supported() { return false; }
 inline int graph_begin_capture(stream_t) { return 1; }
 inline int graph_end_capture(stream_t, graph_t*) { return 1; }
 inline int graph_end_capture_update(stream_t, graph_t*) { return 1; }
+inline void graph_abort_capture(stream_t) {}
 inline int graph_launch(graph_t*, stream_t) { return 1; }
 inline int graph_destroy(graph_t*) { return 0; }
 inline int device_count() { return 1; }

@@ -445,6 +445,21 @@ def check_front_end(dev, fc, L):
     assert rel_l2(dm.istft(Yp.to(dev), L).cpu(), FO.istft(Yp, fc, L)) < 5e-6
 
 
+def check_front_golden(dev, name, fc, L):
+    """The HIP front end against outputs of the reference's own SpecsDataModule (tests/golden/front.npz, oracle/make_golden_front.py):
+    the `log` / `none` spectrogram transforms and the `sqrthann` window next to the defaults (data_module.py:13-19,162-218)."""
+    from sgmse_amd.data_module import SpecsDataModule
+    z = load("front")
+    dm = SpecsDataModule(n_fft=fc.n_fft, hop_length=fc.hop_length, spec_factor=fc.spec_factor,
+                         spec_abs_exponent=fc.spec_abs_exponent, window=fc.window, transform_type=fc.transform_type)
+    sig = synth.synth_waveform(L, seed=5, batch=2)
+    S_ref = torch.from_numpy(z[name + "/stft"])
+    assert rel_l2(dm.stft(sig.to(dev)).cpu(), S_ref) < 5e-6
+    assert rel_l2(dm.spec_fwd(S_ref.to(dev)).cpu(), z[name + "/fwd"]) < 5e-6
+    assert rel_l2(dm.spec_back(torch.from_numpy(z[name + "/fwd"]).to(dev)).cpu(), z[name + "/back"]) < 5e-6
+    assert rel_l2(dm.istft(S_ref.to(dev), L).cpu(), z[name + "/istft"]) < 5e-6
+
+
 def check_enhance(dev, L=8000, N=2):
     """enhancement.py:62-99 end to end (normalise -> STFT -> sampler -> iSTFT -> renormalise) with replayed noise against
     the oracle pipeline; the north-star gate: relative L2 <= 1e-3 on the enhanced waveform."""
@@ -552,7 +567,7 @@ def check_sb_golden(dev, stype, batch=None, use_graph=True):
     reference's own get_sb_sampler + SBVESDE + NCSNpp_v2 (fixture), with replayed noise for 'sde'."""
     z = load(f"sb_{stype}_N4")
     cfg = NO.NetCfg.for_variant("ncsnpp_v2", nf=32)
-    m, _ = make_model(cfg, dev, sde="sbve", k=2.6, c=0.4, N=4, loss_type="data_prediction")
+    m, Pm = make_model(cfg, dev, sde="sbve", k=2.6, c=0.4, N=4, loss_type="data_prediction")
     y, ref = torch.from_numpy(z["y"]), torch.from_numpy(z["out"])
     noise = replay_noise(y.shape, 4) if stype == "sde" else None
     if batch is not None:
@@ -563,11 +578,39 @@ def check_sb_golden(dev, stype, batch=None, use_graph=True):
     out, n = sampler()
     err = rel_l2(out.cpu(), ref)
     print(f"sb_{stype}_N4 on {dev}: rel_l2 vs reference = {err:.3e}")
-    assert n == 4 and err < SAMPLER_TOL, (stype, err)
-    if batch is None:     # the reference-style Python loop over the HIP network agrees with the fused loop (deterministic variant)
-        if stype == "ode":
-            out2, _ = m.get_sb_sampler(m.sde, y.to(dev), sampler_type="ode", n_steps=4, force_python_loop=True)()
-            assert rel_l2(out2.cpu(), out.cpu()) < SAMPLER_TOL   # the bridge weights cancel catastrophically in fp32; GPU pow differs by ulps
+    assert n == 4
+    if stype == "sde":
+        assert err < SAMPLER_TOL, (stype, err)
+        return
+    # 'ode': the reference's first step adds the estimate to 5457 y and cancels (sdes.py:235-313 with k = 2.6, c = 0.4), which turns
+    # a relative difference delta between two implementations' network outputs into ~sqrt(delta * 2e-4) in the state -- the CPU oracle
+    # itself lands 1e-5 ... 7e-5 from the fixture depending on the host's libm (profiles/r03_sb_conditioning.txt, r03_sb_probe.txt).
+    # The state is therefore recorded and only bounded loosely; what is GATED is what the kernels are responsible for: every network
+    # estimate of the reference-style loop against the oracle's network at the SAME input, step by step.
+    from oracle.sde_oracle import SBVE
+    sv = SBVE(2.6, 0.4, 4)
+    sde = m.sde
+    b4 = lambda v: v[:, None, None, None]
+    worst = 0.0
+    with torch.no_grad():
+        xt = y.clone()
+        ts = torch.linspace(sde.T, 1e-4, sde.N + 1)
+        sp, _, sbp, ap, _, _ = sde._sigmas_alphas(ts[0] * torch.ones(xt.shape[0]))
+        for i, t in enumerate(ts[1:]):
+            time = t * torch.ones(xt.shape[0])
+            st, sT, sbt, at, aT, _ = sde._sigmas_alphas(time)
+            est_hip = m(xt.to(dev), y.to(dev), time.to(dev)).cpu()
+            est_orc = NO.score_fn_v2(Pm, cfg, sv, xt, y, time, loss_type="data_prediction")
+            worst = max(worst, rel_l2(est_hip, est_orc))
+            w_prev = at * st * sbt / (ap * sp * sbp + sde.eps)
+            w_est = at / (sT ** 2 + sde.eps) * (sbt ** 2 - sbp * st * sbt / (sp + sde.eps))
+            w_y = at / (aT * sT ** 2 + sde.eps) * (st ** 2 - sp * st * sbt / (sbp + sde.eps))
+            xt = b4(w_prev) * xt + b4(w_est) * est_hip + b4(w_y) * y
+            sp, sbp, ap = st, sbt, at
+    print(f"sb_ode_N4 on {dev}: worst per-step network estimate vs the oracle at the same input = {worst:.3e} (gate {OP_TOL:.0e}); "
+          f"state vs the reference's output: fused loop {err:.3e}, reference-style loop {rel_l2(xt, ref):.3e} (information; bound 1e-3)")
+    assert worst < OP_TOL, worst
+    assert err < 1e-3 and rel_l2(xt, out.cpu()) < 1e-3
 
 
 def check_weight_reload(dev):
@@ -748,6 +791,31 @@ def check_ragged_batch(dev, name="fwd_nf32", frames=(128, 64, 192), sampler=True
         m.get_pc_sampler("reverse_diffusion", "langevin", ys, N=1, snr=0.5, seed=5)()
     with pytest.raises(TypeError):
         m.get_pc_sampler("reverse_diffusion", "ald", ys, N=1, snr=0.5, seed=5, force_python_loop=True)
+
+
+def check_graph_update_path(dev, name="fwd_nf32"):
+    """The captured sampler step under changing ragged compositions and batch sizes: a new composition of the same batch size must
+    bring the instantiated graph up to date IN PLACE (hipGraphExecUpdate: graph_updates grows, or -- if the runtime refuses -- a
+    fresh instantiation: graph_captures grows), never replay a stale executable; every output must equal the eager (graph-free) run
+    of the same call bit for bit, which reads none of the buffers a stale graph would still point at."""
+    cfg = NET_CASES[name]
+    m, _ = make_model(cfg, dev)
+    eng = m.dnn.engine(torch.device(dev))
+    comps = [(128, 64), (64, 192), (192, 64), (128, 128, 64)]
+    c0, u0 = eng.graph_captures(), eng.graph_updates()
+    hist = []
+    for frames in comps:
+        ys = [synth.synth_spec(1, 256, T, seed=11 + i)[0].to(dev) for i, T in enumerate(frames)]
+        ids = [3 + i for i in range(len(frames))]
+        with_graph, _ = m.get_pc_sampler("reverse_diffusion", "ald", ys, N=2, snr=0.5, seed=9, streams=ids, use_graph=True)()
+        hist.append((eng.graph_captures() - c0, eng.graph_updates() - u0))
+        eager, _ = m.get_pc_sampler("reverse_diffusion", "ald", ys, N=2, snr=0.5, seed=9, streams=ids, use_graph=False)()
+        for a, b in zip(with_graph, eager):
+            assert torch.equal(a, b), frames
+    print(f"captured step under {len(comps)} ragged compositions on {dev}: (captures, in-place updates) after each = {hist}")
+    assert hist[0][0] == 1                                                       # the first composition captures
+    for prev, cur in zip(hist, hist[1:]):
+        assert cur[0] + cur[1] == prev[0] + prev[1] + 1, hist                    # every new composition re-captures: update or new instance
 
 
 def check_ragged_variants(dev):

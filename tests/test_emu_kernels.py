@@ -207,6 +207,12 @@ def test_front_end(emu, fc, L):
     P.check_front_end(emu, fc, L)
 
 
+@pytest.mark.parametrize("name", ["hann_exponent", "sqrthann_log", "hann_none", "sqrthann_exponent_48k"])
+def test_front_end_matches_the_reference_data_module(emu, name):
+    from test_oracle_golden import FRONT_CASES
+    P.check_front_golden(emu, name, *FRONT_CASES[name])
+
+
 def test_enhance_end_to_end(emu):
     P.check_enhance(emu, L=8000, N=1)
 

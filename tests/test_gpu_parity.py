@@ -247,6 +247,12 @@ def test_front_end(hip, fc, L):
     P.check_front_end(hip, fc, L)
 
 
+@pytest.mark.parametrize("name", ["hann_exponent", "sqrthann_log", "hann_none", "sqrthann_exponent_48k"])
+def test_front_end_matches_the_reference_data_module(hip, name):
+    from test_oracle_golden import FRONT_CASES
+    P.check_front_golden(hip, name, *FRONT_CASES[name])
+
+
 def test_enhance_end_to_end(hip):
     P.check_enhance(hip, L=8000, N=3)
 
@@ -507,6 +513,10 @@ def test_ragged_launches_over_the_widest_utterances_grid_give_the_same_bits(hip,
     P.check_ragged_batch(hip, "fwd_nf128", frames=(512, 64, 192, 320, 128))
 
 
+def test_captured_step_is_brought_up_to_date_for_every_new_ragged_composition(hip):
+    P.check_graph_update_path(hip)
+
+
 def test_ragged_batches_through_the_other_variants_and_entry_points(hip):
     """ncsnpp_v2 with the new-code score wrapper, ncsnpp_48k, the minibatch wrappers over ragged lists and ScoreModel.enhance_batch
     with waveforms of different lengths: every utterance keeps the bits of its own run (captured graphs on the GPU)."""
@@ -527,3 +537,50 @@ def test_error_behaviour(hip):
     net, _ = P.make_backbone(cfg, hip)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 2, 256, 96, dtype=torch.complex64, device=hip), torch.ones(1, device=hip))   # T % 64 != 0
+
+
+def test_rccl_path_of_the_multi_gpu_job_runs_at_world_size_one(hip):
+    """What `bench.py --gpus N` and the directory job do per rank with the `nccl` (= RCCL) backend, executed once on the one GPU this box
+    has: init_process_group with a bound device, the 262 MB weight broadcast of the full-width network (the early return for a single
+    rank bypassed), the device-bound barrier and the fp64 all_gather of the per-rank times -- so that library loading, device binding
+    and the collectives have run on hardware before an 8-GPU run ever happens.  Child process: the process group must not leak into
+    this one.  Reference pattern: model.py:208-223 (contiguous per-rank shards, no data-path collective)."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = r"""
+import os, sys, time, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import torch.distributed as dist
+import parity as P
+from oracle import ncsnpp_oracle as NO
+from sgmse_amd import _lib
+from sgmse_amd.parallel import broadcast_backbone_weights, shard_range
+_lib.load_library()
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29517')
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == 'nccl'
+net, _ = P.make_backbone(NO.NetCfg.for_variant('ncsnpp'), 'cuda')
+z = P.load('fwd_nf128')
+x, t = torch.from_numpy(z['x']).cuda(), torch.from_numpy(z['t']).cuda()
+before = net(x, t).cpu()
+n = sum(v.numel() for v in net.state_dict().values())
+torch.cuda.synchronize(); t0 = time.perf_counter()
+broadcast_backbone_weights(net, src=0, force=True)
+torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3
+dist.barrier(device_ids=[0])
+tt = torch.tensor([1.25], device=dev, dtype=torch.float64)
+every = [torch.zeros_like(tt)]
+dist.all_gather(every, tt)
+assert float(every[0].item()) == 1.25
+after = net(x, t).cpu()
+assert torch.equal(before, after), 'weights changed by a broadcast from the only rank'
+assert shard_range(256, 0, 1) == (0, 256)
+dist.destroy_process_group()
+print('RCCL-OK params %%d (%%.0f MB) broadcast %%.1f ms' %% (n, n * 4 / 1e6, ms))
+""" % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    print(out.stdout[-400:])
+    assert "RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

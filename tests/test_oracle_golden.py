@@ -103,6 +103,28 @@ def test_front_end_self_consistency(fc, L):
     assert Y.shape[-1] % 64 == 0
 
 
+FRONT_CASES = {   # oracle/make_golden_front.py
+    "hann_exponent": (FO.FrontCfg(), 6000),
+    "sqrthann_log": (FO.FrontCfg(window="sqrthann", transform_type="log"), 6000),
+    "hann_none": (FO.FrontCfg(transform_type="none"), 6000),
+    "sqrthann_exponent_48k": (FO.FrontCfg(n_fft=1534, hop_length=384, window="sqrthann", spec_factor=0.065, spec_abs_exponent=0.667, sr=48000), 9000),
+}
+
+
+@pytest.mark.parametrize("name", list(FRONT_CASES))
+def test_front_end_matches_the_reference_data_module(name):
+    """stft / spec_fwd / spec_back / istft of the reference's own SpecsDataModule (data_module.py:13-19,162-218) for the `log` and `none`
+    transforms and the `sqrthann` window as well as the defaults: the oracle must reproduce the stored outputs."""
+    fc, L = FRONT_CASES[name]
+    z = load("front")
+    sig = synth.synth_waveform(L, seed=5, batch=2)
+    S = torch.from_numpy(z[name + "/stft"])
+    assert rel_l2(FO.stft(sig, fc), S) < 1e-6
+    assert rel_l2(FO.spec_fwd(S, fc), z[name + "/fwd"]) < 1e-6
+    assert rel_l2(FO.spec_back(torch.from_numpy(z[name + "/fwd"]), fc), z[name + "/back"]) < 1e-6
+    assert rel_l2(FO.istft(S, fc, L), z[name + "/istft"]) < 1e-6
+
+
 @pytest.mark.parametrize("stype", ["ode", "sde"])
 def test_sb_sampler_matches_reference(stype):
     z = load(f"sb_{stype}_N4")
