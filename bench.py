@@ -37,6 +37,14 @@ DOMINANT = {   # conv split mode -> (kernel, effective peak, how the peak is der
         MFMA16_PEAK_TFLOPS / 6, "dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per multiply", "void sgmse::conv3x3_split_kernel<sgmse::SplitB3, 0, 1, 0"),
     2: ("conv3x3_split_kernel<SplitH2> (3x3 implicit GEMM, fp16x2 operand split, 3 partial products, fp32 accumulate)",
         MFMA16_PEAK_TFLOPS / 3, "dense f16 MFMA peak 2500 TFLOP/s / 3 partial products per multiply", "void sgmse::conv3x3_split_kernel<sgmse::SplitH2, 0, 1, 0"),
+    # split mode 2 with the Winograd kernel on the wide levels (the default since round 4).  `peak` stays the ceiling of the DIRECT form
+    # -- what an algorithmic multiply costs on this pipe without the transform, the yardstick of rounds 1-3 -- and the line also carries
+    # the ceiling of the form that actually runs (F(2,3) along T: 12 instead of 18 K-steps per output pair, i.e. 2 MFMA multiplies per
+    # algorithmic multiply instead of 3)
+    3: ("conv3x3_wino_kernel<8,...> (3x3 implicit GEMM, 1-D Winograd F(2,3) along T x fp16x2 operand split, fp32 accumulate; the levels "
+        "below 64 x 128 stay on conv3x3_split_kernel<SplitH2>)",
+        MFMA16_PEAK_TFLOPS / 3, "dense f16 MFMA peak 2500 TFLOP/s / 3 partial products per algorithmic multiply (direct form)",
+        "void sgmse::conv3x3_wino_kernel<8, 1, 0"),
 }
 HBM_PEAK_GBS = 8000.0
 
@@ -187,7 +195,7 @@ def hbm_traffic_of_dominant_kernel(prefix):
         for k, v in d.items():
             if k.startswith(prefix):
                 alg = d.get("_algorithmic_bytes_per_launch_of_the_benchmarked_conv")
-                note = f"{os.path.basename(f)}: 3x3 128->128 @256x512, B=8, fused producer+residual epilogue"
+                note = f"{os.path.basename(f)}: 3x3 128->128 @256x512, B=8, fused producer+residual epilogue, median {v.get('median_duration_us_under_pmc')} us under the counters"
                 return v["hbm_bytes_per_launch"], note + (f"; algorithmic bytes of that launch = {alg:.4g}" if alg else "")
     return None, "no committed PMC profile holds the dominant kernel"
 
@@ -344,14 +352,20 @@ def measure(env, a, workload, batch, steps, warmup, sampler=None, N=None, snr=No
         prof, _ = ctx.profile_forward(Y, tt)
         dom = prof["conv3x3_wide"]
         ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        kname, peak, peak_note, prefix = DOMINANT[ctx.conv_split_mode()]
+        wino = ctx.conv_split_mode() == 2 and ctx.conv_winograd()
+        kname, peak, peak_note, prefix = DOMINANT[3 if wino else ctx.conv_split_mode()]
         traffic, traffic_note = hbm_traffic_of_dominant_kernel(prefix)
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak, "traffic": traffic, "traffic_note": traffic_note,
+                           "traffic_source": "committed rocprofv3 PMC passes over the kernel micro-benchmark at the dominant layer shape "
+                                             "(not counters of this run: rocprofv3 --pmc does not survive the full bench command)",
                            "kernel": kname, "peak_note": peak_note, "achieved_vs_fp32_mfma_peak": ach / FP32_PEAK_TFLOPS,
                            "launches_per_eval": dom["launches"],
                            "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),
                            "flop_per_launch_avg": dom["work"] / max(dom["launches"], 1)}
+        if wino:
+            out["roofline"]["peak_of_the_winograd_form"] = MFMA16_PEAK_TFLOPS / 2
+            out["roofline"]["frac_of_the_winograd_form"] = ach / (MFMA16_PEAK_TFLOPS / 2)
         classes = {}
         for k, v in prof.items():
             rate = v["work"] / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0

@@ -146,6 +146,10 @@ int sgmse_op_attention(sgmse_ctx* ctx, const float* qkv, float* out, int B, int 
 /* which kernel family the wide 3x3 layers use in this context: 0 fp32 MFMA, 1 bf16x3 split, 2 fp16x2 split
  * (SGMSE_CONV_SPLIT, read at configure time; kernels_conv_split.h) */
 int sgmse_conv_split_mode(sgmse_ctx* ctx, int* out);
+/* 1 when the levels of >= 32 tiles per image run their full 3x3 layers on the Winograd F(2,3) x fp16x2 kernel (split mode 2 and
+ * SGMSE_WINO != 0; kernels_conv_wino.h), else 0.  Like the split mode it replaces nothing in the reference (F.conv2d picks its own
+ * algorithm, layers.py:118-124); bench.py names the dominant kernel by it. */
+int sgmse_conv_winograd(sgmse_ctx* ctx, int* out);
 
 /* -- measurement: one eager forward with HIP events (on the context's stream) around every kernel launch, summed per
  *    kernel class.  ms, work and launches are host arrays of SGMSE_NCLASS entries:

@@ -64,6 +64,7 @@ _SIGS = {
     "sgmse_op_conv2d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _P, _I]),
     "sgmse_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I]),
     "sgmse_conv_split_mode": (_I, [_P, _P]),
+    "sgmse_conv_winograd": (_I, [_P, _P]),
     "sgmse_op_fir": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "sgmse_op_attention": (_I, [_P, _P, _P, _I, _I, _I]),
     "sgmse_profile_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(_I)]),
@@ -414,6 +415,12 @@ class Context:
         self.use_current_stream()
         self.check(self.lib.sgmse_bench_conv(self.h, ks, B, Cin, Cout, H, W, variant, iters, int(fused), C.byref(ms)))
         return ms.value
+
+    def conv_winograd(self) -> bool:
+        """True when the wide levels' 3x3 layers run on the Winograd F(2,3) x fp16x2 kernel (kernels_conv_wino.h)."""
+        out = C.c_int(0)
+        self.check(self.lib.sgmse_conv_winograd(self.h, C.byref(out)))
+        return bool(out.value)
 
     def conv_split_mode(self) -> int:
         """0: fp32 MFMA, 1: bf16x3 split, 2: fp16x2 split on the wide 3x3 layers (kernels_conv_split.h)."""

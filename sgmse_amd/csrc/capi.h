@@ -173,6 +173,11 @@ int sgmse_conv_split_mode(sgmse_ctx* ctx, int* out) {
   return sg_guard(ctx, [&](sgmse::Engine& e) { *out = e.split_mode(); });
 }
 
+int sgmse_conv_winograd(sgmse_ctx* ctx, int* out) {
+  SG_ARG(ctx, out != nullptr, "out is null");
+  return sg_guard(ctx, [&](sgmse::Engine& e) { *out = e.winograd() ? 1 : 0; });
+}
+
 int sgmse_op_fir(sgmse_ctx* ctx, const float* x, float* out, int BC, int H, int W, int up, const float* in_scale,
                  const float* in_shift, int in_act, float* out_raw) {
   SG_ARG(ctx, x && out && BC > 0 && H > 0 && W > 0, "null pointer or non-positive shape");

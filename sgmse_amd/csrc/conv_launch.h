@@ -45,10 +45,19 @@ inline void launch_conv_mfma_t(const ConvArgs& a, drt::stream_t st, int variant,
     const bool pipe = ((variant & 4) != 0) != (SGMSE_CONV_PIPE_DEFAULT != 0);
     if (vec && pipe) { DRT_LAUNCH((conv_mfma_pipe_kernel<KS, WC, FC, FP>), grid, dim3(256), st, a); return; }
   }
-  if (vec && pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 1>), grid, dim3(256), st, a);
-  else if (vec) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 1>), grid, dim3(256), st, a);
-  else if (pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 0>), grid, dim3(256), st, a);
-  else DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 0>), grid, dim3(256), st, a);
+  if constexpr (KS == 1 && FC * FP == 8) {
+    // the element-wise staged 1x1 kernel on its widest tile needs more than 256 registers (it spilled): inputs that cannot take the
+    // float4 path (width not a multiple of 4, unaligned sources) run on the 4-row tile -- the same bits, every tile shape accumulates
+    // an output in the same order
+    if (!vec) { launch_conv_mfma_t<KS, WC, FC, FP / 2>(a, st, variant, ksplit); return; }
+    if (pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 1>), grid, dim3(256), st, a);
+    else DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 1>), grid, dim3(256), st, a);
+  } else {
+    if (vec && pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 1>), grid, dim3(256), st, a);
+    else if (vec) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 1>), grid, dim3(256), st, a);
+    else if (pref) DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 1, 0>), grid, dim3(256), st, a);
+    else DRT_LAUNCH((conv_mfma_kernel<KS, WC, FC, FP, 0, 0>), grid, dim3(256), st, a);
+  }
   if constexpr (FC * FP <= 2) {
     if (ksplit > 1) DRT_LAUNCH((conv_splitk_reduce_kernel<KS, WC, FC, FP>), dim3(grid.x, grid.y, 1), dim3(256), st, a, ksplit);
   }
@@ -162,9 +171,9 @@ inline void launch_conv_wino(const ConvArgs& a, drt::stream_t st, bool rows4, bo
 #define SGMSE_WABL_CASE(V) if (abl == V) { DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0, 0, V>), dim3(conv_grid_tiles(a, 8), a.Cout / 128, 1), dim3(512), st, a); return; }
   SGMSE_WABL_CASE(1) SGMSE_WABL_CASE(2) SGMSE_WABL_CASE(4) SGMSE_WABL_CASE(8) SGMSE_WABL_CASE(16) SGMSE_WABL_CASE(24) SGMSE_WABL_CASE(3) SGMSE_WABL_CASE(32) SGMSE_WABL_CASE(20)
 #undef SGMSE_WABL_CASE
-#endif
-  (void)abl;
   if (trace) { DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0, 1>), dim3(conv_grid_tiles(a, 8), a.Cout / 128, 1), dim3(512), st, a); return; }
+#endif
+  (void)abl; (void)trace;
   if (rows4) {
     const dim3 grid(conv_grid_tiles(a, 4), a.Cout / 128, 1);
     if (a.sc_w) DRT_LAUNCH((conv3x3_wino_kernel<4, 1, 1>), grid, dim3(512), st, a);

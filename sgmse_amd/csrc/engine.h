@@ -250,7 +250,7 @@ struct ConvW {            // one convolution's parameters on the device
                                    // would otherwise leave most CUs idle (the 16x32 ... 4x8 levels of the U-Net)
   const float* packed_split = nullptr; // split-kernel fragment layout (kernels_conv_split.h) in the engine's split mode,
                                        // 3x3 with cout % 128 == 0, cin % 16 == 0
-  const float* split_scale = nullptr;  // fp16x2: device scalar 2^-(k+4) behind the packed fragments
+  const float* split_scale = nullptr;  // fp16x2: per output channel the factor undoing its weights' power-of-two scale (table behind the fragments)
   int split_mode = 0;                  // 1 bf16x3, 2 fp16x2 (0: no split layout)
   const float* packed_wino = nullptr;  // Winograd F(2,3) x fp16x2 fragment layout (kernels_conv_wino.h), 3x3 with cout % 128 == 0, cin % 16 == 0
   const float* wino_scale = nullptr;   // ... and the per-output-channel factors behind it
@@ -512,6 +512,7 @@ class Engine {
   int graph_captures() const { return graph_captures_; }     // how many times a step was captured + instantiated (tests, bench)
   int graph_updates() const { return graph_updates_; }       // ... captured and applied to the existing executable in place
   int split_mode() const { return split_mode_; }
+  bool winograd() const { return split_mode_ == 2 && wino_; }
   size_t arena_bytes() const { return arena_cap_; }
 
   // ---- single ops (op-level C ABI + tests) ------------------------------------------------------------------
@@ -562,7 +563,7 @@ class Engine {
       SG_REQUIRE(conv_split_eligible(ks, a.C1, C2, Cout) || conv_thin_split_eligible(ks, a.C1, C2, Cout),
                  "op_conv2d: shape is not eligible for the split kernels");
       const int smode = force_direct - 1;
-      const float* pk = pack_split(w_oihw, ks, Cin, Cout, smode, false, &a.acc_scale);
+      const float* pk = pack_split(w_oihw, ks, Cin, Cout, smode, false, &a.co_scale);
       a.w = pk;
       float *bounds = nullptr, *xb = nullptr;
       if (smode == 2) {      // dynamic input scale: range bounds as the producers would have left them
@@ -706,7 +707,7 @@ class Engine {
     const float* pk3 = nullptr;
     float *bounds = nullptr, *xbound = nullptr;
     if (b3) {
-      pk3 = pack_split(w, ks, Cin, Cout, smode, false, &a.acc_scale); a.w = pk3;
+      pk3 = pack_split(w, ks, Cin, Cout, smode, false, &a.co_scale); a.w = pk3;
       if (smode == 2) {
         bounds = input_bounds(x, Cin, nullptr, 0, B, H * W);
         if (ks == 1) {
@@ -902,18 +903,18 @@ class Engine {
   const float* pack_split(const float* oihw, int ks, int cin, int cout, int mode, bool weight_owned, const float** scale_out) {
     const int taps = ks * ks;
     const size_t frags = mode == 2 ? packed_split_frags<SplitH2>(cin, cout, taps) : packed_split_frags<SplitB3>(cin, cout, taps);
-    const size_t bytes = frags * 16 + 16;
+    const int cout_pad = (cout + 127) / 128 * 128;
+    const size_t bytes = frags * 16 + (size_t)cout_pad * 8;             // [fragments][per-channel inverse scales][scales (packing scratch)]
     uint32_t* pk = static_cast<uint32_t*>(weight_owned ? dev_alloc_w(bytes) : dev_alloc_tmp(bytes));
     PackSplitArgs pa{oihw, pk, cin, cout, frags, nullptr, taps};
     const dim3 grid((unsigned)((frags + 255) / 256));
     if (mode == 2) {
-      float* amax = reinterpret_cast<float*>(pk) + frags * 4 + 1;     // scratch word behind the scale
-      SG_CHECK(drt::memset_dev(amax, 0, 4, stream_));
-      const size_t n = (size_t)cout * cin * taps;
-      DRT_LAUNCH(absmax_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), stream_, oihw, n, amax);
-      pa.absmax = amax;
+      float* inv = reinterpret_cast<float*>(pk) + frags * 4;
+      float* sc = inv + cout_pad;
+      DRT_LAUNCH(split_co_scale_kernel, dim3((unsigned)((cout_pad + 255) / 256)), dim3(256), stream_, oihw, cin * taps, cout, cout_pad, inv, sc);
+      pa.co_scale = sc;
       DRT_LAUNCH(pack_weights_split_kernel<SplitH2>, grid, dim3(256), stream_, pa);
-      *scale_out = reinterpret_cast<const float*>(pk) + frags * 4;
+      *scale_out = inv;
     } else {
       DRT_LAUNCH(pack_weights_split_kernel<SplitB3>, grid, dim3(256), stream_, pa);
       *scale_out = nullptr;
@@ -1360,7 +1361,7 @@ class Engine {
       fl += 2.0 * B_ * (double)w.cout * Cs * a.H * a.W;
     }
     if (use_split) {
-      ca.w = w.packed_split; ca.acc_scale = w.split_scale;
+      ca.w = w.packed_split; ca.co_scale = w.split_scale;      // (null for bf16x3: no scale)
       if (w.ks == 1 && w.split_mode == 2) { ca.amax1 = a.amax; ca.amax2 = b ? b->amax : nullptr; }
       if (w.ks == 3 && w.split_mode == 2) ca.xbound = xf.bound;
       // 4-row workgroups when 8-row ones would leave CUs idle (bit-identical results, so this may follow the batch size)
@@ -1714,40 +1715,33 @@ class Engine {
   Arena arena_; char* arena_base_ = nullptr; size_t arena_cap_ = 0;
   bool dry_ = false;
   // measurement knobs, re-read from the environment at every configure (so one process can compare settings)
+  // Runtime switches, re-read from the environment at every configure / weight load (so one process can compare settings).
+  // User-facing: SGMSE_CONV_SPLIT, SGMSE_WINO, SGMSE_CONV_XCD_MAP, SGMSE_RAGGED_PREFIX, SGMSE_DEBUG_SYNC,
+  // SGMSE_PROFILE_DUMP.  Test hooks (what the bitwise / parity tests toggle to reach a code path; not for users):
+  // SGMSE_TILE_MIN_BLOCKS, SGMSE_SPLIT_MIN_TILES, SGMSE_WINO_MIN_TILES, SGMSE_FUSE_GN_STATS, SGMSE_POISON, SGMSE_CONV_VARIANT.
+  // Everything else that used to be a switch is a constant now: the losing side of each was measured and removed (round 4).
   void read_knobs() {
     auto flag = [](const char* name, bool dflt) { const char* e = getenv(name); return e ? e[0] == '1' : dflt; };
-    const char* e = getenv("SGMSE_TILE_MIN_BLOCKS");
-    tile_min_blocks_ = e ? atol(e) : 512L;               // profiles/r01_tile_sweep.txt
-    prof_dump_ = flag("SGMSE_PROFILE_DUMP", false);      // per-launch lines from profile_forward
-    fir_scalar_ = flag("SGMSE_FIR_SCALAR", false);       // per-pixel FIR kernels everywhere
-    e = getenv("SGMSE_CONV_SPLIT");                      // 0: fp32 MFMA only, 1: bf16x3, 2: fp16x2 on the wide levels
+    const char* e = getenv("SGMSE_CONV_SPLIT");          // 0: fp32 MFMA only, 1: bf16x3, 2: fp16x2 (+ Winograd, see SGMSE_WINO) on the wide levels
     split_mode_ = e ? atoi(e) : SGMSE_CONV_SPLIT_DEFAULT;
     SG_REQUIRE(split_mode_ >= 0 && split_mode_ <= 2, "SGMSE_CONV_SPLIT must be 0, 1 or 2");
-    e = getenv("SGMSE_SPLIT_MIN_TILES");
-    split_min_tiles_ = e ? atol(e) : 8L;                    // per-image 8x32 tiles from which a layer uses it (profiles/r01_b3_threshold.txt)
-    fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue
-    coarse_chunked_ = flag("SGMSE_COARSE_CHUNKED", true);
-    poison_ = flag("SGMSE_POISON", false);
+    wino_ = flag("SGMSE_WINO", true);                    // Winograd F(2,3) x fp16x2 kernel on the wide levels (0: the direct fp16x2 split kernel there too)
     // ragged convolution launches over the tiles that exist (ConvArgs::rag_cols) and the XCD-aware tile order of the convolution
     // kernels (ConvArgs::xcd_map): both bit-identical, both measured in round 4 (profiles/r04_knobs_ab.txt: ragged batches 1.15 -> 1.04x
     // per frame; +3.5-4 % at T = 512 and T = 448) and on since
     rag_prefix_ = flag("SGMSE_RAGGED_PREFIX", true);
     conv_xcd_map_ = flag("SGMSE_CONV_XCD_MAP", true);
-    wino_ = flag("SGMSE_WINO", true);                       // Winograd F(2,3) x fp16x2 kernel on the wide levels (0: the direct fp16x2 split kernel there too)
+    debug_sync_ = flag("SGMSE_DEBUG_SYNC", false);       // synchronise after every launch of the forward and print its label (stderr)
+    prof_dump_ = flag("SGMSE_PROFILE_DUMP", false);      // per-launch lines from profile_forward
+    // ---- test hooks
+    e = getenv("SGMSE_TILE_MIN_BLOCKS");
+    tile_min_blocks_ = e ? atol(e) : 512L;               // workgroups below which a launch takes the smaller tile shape (profiles/r01_tile_sweep.txt)
+    e = getenv("SGMSE_SPLIT_MIN_TILES");
+    split_min_tiles_ = e ? atol(e) : 8L;                 // per-image 8x32 tiles from which a layer uses a split kernel (profiles/r01_b3_threshold.txt)
     e = getenv("SGMSE_WINO_MIN_TILES");
-    wino_min_tiles_ = e ? atol(e) : 32L;                    // ... from this many 8 x 32 tiles per nominal image (32: the 64 x 128 level and up)
-    debug_sync_ = flag("SGMSE_DEBUG_SYNC", false);          // synchronise after every launch of the forward and print its label (stderr)
-    entry_mfma_ = flag("SGMSE_ENTRY_MFMA", true);           // entry convolution on the fp32 MFMA kernel (input channels padded to 8)
-    fold_shortcut_ = flag("SGMSE_FOLD_SHORTCUT", true);
-    coarse_split_ = flag("SGMSE_COARSE_SPLIT", true);        // chunked 4-row fp16x2 split kernel for levels of few tiles per image
-    e = getenv("SGMSE_CHUNK_MAX_TILES");                    // ... up to this many 8x32 tiles per image (2: the 16 x 32 level only)
-    chunk_max_tiles_ = e ? atol(e) : 8L;                    //     (8: the 16 x 32 and 32 x 64 levels of a 256 x 512 input)
-    e = getenv("SGMSE_CHUNK_MIN_TILES");                    //     from this many tiles and images at least SGMSE_CHUNK_MIN_WIDTH wide: the 8 x 16 and
-    chunk_min_tiles_ = e ? atol(e) : 2L;                    //     4 x 8 levels (1 tile, half / three quarters of each 32-pixel fragment row masked)
-    e = getenv("SGMSE_CHUNK_MIN_WIDTH");                    //     measured +0.8 % / +1.4 % at batch 32 and -2 % / -5 % at batch 1: left on the fp32 kernels
-    chunk_min_width_ = e ? atoi(e) : 32;                    //     (profiles/r02_chunk_splitk.txt)
-    e = getenv("SGMSE_COARSE_SPLITK_DIV");                  // ... whose chunks go to separate workgroups below tile_min_blocks / this
-    coarse_splitk_div_ = e ? atol(e) : 4L;                  //     (batch 1: 0.503 -> 0.457 s per utterance, profiles/r02_chunk_splitk.txt)
+    wino_min_tiles_ = e ? atol(e) : 32L;                 // ... and the Winograd kernel (32: the 64 x 128 level and up)
+    fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue (0: stand-alone statistics passes)
+    poison_ = flag("SGMSE_POISON", false);               // NaN patterns in every allocation and in the arena before every forward
   }
   // per-forward range-bound slots ([B][kAmaxSpread] floats each), handed out in program order; counted by the dry run
   float* amax_pool_ = nullptr; size_t amax_pool_floats_ = 0; int amax_slots_ = 0, amax_next_ = 0;
@@ -1760,16 +1754,18 @@ class Engine {
     return amax_pool_ + (size_t)i * B_ * kAmaxSpread;
   }
   long tile_min_blocks_ = 512, split_min_tiles_ = 8;
-  bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true, entry_mfma_ = true;
+  // (settled in rounds 2-3, switches removed in round 4: chunked accumulation of the coarse fp32 layers, shortcuts folded into the 3x3
+  //  launches, chunked 4-row fp16x2 kernel on the 16 x 32 / 32 x 64 levels, entry convolution on the MFMA kernel)
+  static constexpr bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true, entry_mfma_ = true;
   ConvW entry8_{}; int entry8_idx_ = -1;
   bool poison_ = false, debug_sync_ = false, conv_xcd_map_ = true, rag_prefix_ = true, wino_ = true;
   long wino_min_tiles_ = 32;
-  long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8, chunk_min_tiles_ = 2;
-  int chunk_min_width_ = 32;
+  static constexpr long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8, chunk_min_tiles_ = 2;      // (profiles/r02_chunk_splitk.txt)
+  static constexpr int chunk_min_width_ = 32;
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};
-  bool fir_scalar_ = false;
+  static constexpr bool fir_scalar_ = false;      // (per-pixel FIR kernels everywhere: a round-1 measurement switch)
   bool fuse_gn_stats_ = true;
   int B_ = 0, shape_B_ = 0, shape_F_ = 0, shape_T_ = 0;
   float2 *sx_ = nullptr, *sxm_ = nullptr, *sscore_ = nullptr, *sy_ = nullptr; size_t samp_n_ = 0;

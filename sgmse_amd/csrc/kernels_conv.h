@@ -320,10 +320,11 @@ __device__ __forceinline__ void conv_acc_raw(const ConvArgs& p, int b, int co_bl
     for (int r = 0; r < 16; ++r) { const int co = co_l + (r & 3) + 8 * (r >> 2); init[r] += b2[co < p.Cout ? co : 0]; }
   }
 }
+// factor that takes an accumulator of output channel co back to the unscaled convolution (before the per-utterance input factor):
+// per channel for the fp16x2 kernels (ConvArgs::co_scale, a table padded to whole 128-channel blocks), else the layer's scalar or 1
+__device__ __forceinline__ float conv_as(const ConvArgs& p, int co) { return p.co_scale ? p.co_scale[co] : (p.acc_scale ? *p.acc_scale : 1.0f); }
 template <class T>
 __device__ __forceinline__ void conv_acc_init(const ConvArgs& p, int b, int co_blk, int frag, int kh, float as_mul, float (&init)[16]) {
-  const float as = (p.acc_scale ? *p.acc_scale : 1.0f) * as_mul;
-  const float inv = 1.0f / as;
   const float* b2 = nullptr;
   if (p.bias2) {
     const int step = p.step_ptr ? *p.step_ptr : 0;
@@ -341,7 +342,7 @@ __device__ __forceinline__ void conv_acc_init(const ConvArgs& p, int b, int co_b
     for (int r = 0; r < 16; ++r) { const int co = co_l + (r & 3) + 8 * (r >> 2); init[r] += b2[co < p.Cout ? co : 0]; }
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) init[r] *= inv;
+  for (int r = 0; r < 16; ++r) init[r] *= 1.0f / (conv_as(p, co_l + (r & 3) + 8 * (r >> 2)) * as_mul);      // (powers of two: exact)
 }
 
 // Epilogue shared by the MFMA kernels: D[co = regs][px = lanes] -> NCHW rows, + bias, + time-embedding bias row,
@@ -356,9 +357,9 @@ __device__ __forceinline__ void conv_acc_init(const ConvArgs& p, int b, int co_b
 // 16, 8, 7 (mirror), 1 a lane owns ONE of the 16 registers summed over 16 lanes, and the final ^2 step completes it.
 // The order of the additions is a function of (row, segment) only -- not of the tile shape, wave or workgroup -- so the
 // statistics, and everything computed from them, do not depend on which tile shape a launch used.
-template <class T, int FC, int FP, int WC, bool GUARD, int ABL, bool PRE, bool RES, bool STAT4>
+template <class T, int FC, int FP, int WC, bool GUARD, int ABL, bool PRE, bool RES, bool STAT4, bool CSV>
 __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&acc)[FC][FP], int b, int co_blk, int tx, int ty,
-                                                    int tiles_x, int wc, int wp, int l31, int kh, float as) {
+                                                    int tiles_x, int wc, int wp, int l31, int kh, float as, float as_mul) {
   constexpr int CO_T = T::CO_T, ROWS = T::ROWS;
   constexpr int PF = (ABL & 128) ? 1 : (FP < 4 ? FP : 4);   // residual rows in flight (16 registers each)
   constexpr int AUX = (ABL & 256) ? 2 : 0;
@@ -383,6 +384,12 @@ __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&
     // byte offset of (channel co_l, row yb, column x) inside the utterance; < 2^31 for every tensor of this network
     const unsigned lane_boff = (((unsigned)co_l * (unsigned)H + (unsigned)yb) * (unsigned)W + (unsigned)x) * 4u;
     auto soff = [&](int r) -> unsigned { return (unsigned)((r & 3) + 8 * (r >> 2)) * HW * 4u; };
+    // CSV: the accumulator factor is per output channel (fp16x2 weights carry a power-of-two scale per channel: ConvArgs::co_scale)
+    float asv[CSV ? 16 : 1];
+    if constexpr (CSV) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asv[r] = p.co_scale[co_l + (r & 3) + 8 * (r >> 2)] * as_mul;      // (table padded to whole blocks: no guard)
+    }
     // per-channel additive terms (conv bias + time-embedding row): two batches of independent loads, each under ONE uniform
     // branch (a branch per element serialises 32 loads behind vmcnt(0) waits); PRE: already in the accumulators
     float bv[16];
@@ -430,7 +437,7 @@ __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&
       float sv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = acc[i][j][r] * as;
+        float v = acc[i][j][r] * (CSV ? asv[CSV ? r : 0] : as);
         if constexpr (!PRE) v += bv[r];
         if constexpr (has_res) v += rr[j % PF][r];
         v *= p.out_scale;
@@ -492,7 +499,8 @@ __device__ __forceinline__ float conv_epilogue_body(const ConvArgs& p, f32x16 (&
 // cache policy on the residual loads and output stores
 // PRE: the kernel initialised its accumulators with (bias + bias2) / as (conv_acc_init), the epilogue adds no bias
 // STAT4: GroupNorm partials per 4 image rows (ConvArgs::stats_rows == 4; needs FP % 4 == 0: a wave's rows are whole sub-tiles)
-template <class T, int FC, int FP, int WC, int ABL = 0, bool PRE = false, bool STAT4 = false>
+// CSV: per-output-channel accumulator factors (ConvArgs::co_scale; the fp16x2 kernels) instead of the layer's scalar
+template <class T, int FC, int FP, int WC, int ABL = 0, bool PRE = false, bool STAT4 = false, bool CSV = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[FC][FP], int b, int co_blk, int tx, int ty,
                                               int tiles_x, int wc, int wp, int l31, int kh, float as_mul = 1.0f) {
   static_assert(!STAT4 || FP % 4 == 0, "4-row statistics sub-tiles need 4 or 8 rows per wave");
@@ -502,11 +510,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[F
   const bool res = p.res != nullptr && !(ABL & 2);
   float vmax;
   if (inside) {
-    if (res) vmax = conv_epilogue_body<T, FC, FP, WC, false, ABL, PRE, true, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
-    else vmax = conv_epilogue_body<T, FC, FP, WC, false, ABL, PRE, false, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
+    if (res) vmax = conv_epilogue_body<T, FC, FP, WC, false, ABL, PRE, true, STAT4, CSV>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as, as_mul);
+    else vmax = conv_epilogue_body<T, FC, FP, WC, false, ABL, PRE, false, STAT4, CSV>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as, as_mul);
   } else {
-    if (res) vmax = conv_epilogue_body<T, FC, FP, WC, true, ABL, PRE, true, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
-    else vmax = conv_epilogue_body<T, FC, FP, WC, true, ABL, PRE, false, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as);
+    if (res) vmax = conv_epilogue_body<T, FC, FP, WC, true, ABL, PRE, true, STAT4, CSV>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as, as_mul);
+    else vmax = conv_epilogue_body<T, FC, FP, WC, true, ABL, PRE, false, STAT4, CSV>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as, as_mul);
   }
   if (p.amax_out) {      // wave-uniform
 #pragma unroll
@@ -876,7 +884,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs p, int
   // chunks of the fp16x2 kernel carry its per-utterance input scale (ConvArgs::xbound); the fp32 kernels' chunks carry none
   float as_mul = 1.0f;
   if (p.xbound) as_mul = 1.0f / h2_weight_scale(amax_read(p.xbound, b));
-  conv_epilogue<T, FC, FP, WC, 0, false, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as_mul);
+  conv_epilogue<T, FC, FP, WC, 0, false, STAT4, STAT4>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kh, as_mul);      // (STAT4 = the chunked fp16x2 kernel's reduce: per-channel factors)
 }
 
 // Direct (VALU) convolution: one thread per output pixel, CG output channels per thread.

@@ -108,9 +108,19 @@ struct ConvSplitGeom {
 };
 
 // Weight packing.  src: OIHW fp32 [Cout][Cin][k][k] (taps = k*k = 9 or 1); dst: u32x4 [nCoBlk][Cin/16][taps][NS][4][64], followed (SplitH2) by
-// one float: the factor 2^-k that undoes the weights' scale (the input's per-utterance scale is undone by the kernel).  `absmax` (device,
-// SplitH2 only) = max |w| of the layer, from absmax_kernel.  One thread per 16-byte fragment element.
-struct PackSplitArgs { const float* src; uint32_t* dst; int cin, cout; size_t total; const float* absmax; int taps; };
+// nCoBlk * 128 floats: PER OUTPUT CHANNEL the factor 2^-k that undoes that channel's weight scale (the input's per-utterance scale is
+// undone by the kernel) -- one outlier weight costs the small weights of its own channel their low bits, not the whole layer's.
+// `co_scale` (device, SplitH2 only) = the channels' scales 2^k, from split_co_scale_kernel.  One thread per 16-byte fragment element.
+struct PackSplitArgs { const float* src; uint32_t* dst; int cin, cout; size_t total; const float* co_scale; int taps; };
+// per output channel: scale 2^k with max |w| 2^k in [2^13, 2^14), and its inverse (padded channels: 1)
+__global__ __launch_bounds__(256) void split_co_scale_kernel(const float* src, int n_per_co, int cout, int cout_pad, float* inv_scale, float* scale) {
+  const int co = blockIdx.x * 256 + threadIdx.x;
+  if (co >= cout_pad) return;
+  float m = 0.f;
+  if (co < cout) for (int i = 0; i < n_per_co; ++i) m = fmaxf(m, fabsf(src[(size_t)co * n_per_co + i]));
+  const float sc = co < cout ? h2_weight_scale(m) : 1.f;
+  scale[co] = sc; inv_scale[co] = 1.f / sc;
+}
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t n, float* out) {   // *out zeroed by the caller
   float m = 0.f;
@@ -124,11 +134,6 @@ template <class S>
 __global__ __launch_bounds__(256) void pack_weights_split_kernel(PackSplitArgs p) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= p.total) return;
-  float wscale = 1.f;
-  if (S::SCALED) {
-    wscale = h2_weight_scale(*p.absmax);
-    if (e == 0) reinterpret_cast<float*>(p.dst)[p.total * 4] = 1.f / wscale;   // the consumers' input scales are per utterance and undone by them
-  }
   const int lane = (int)(e & 63);
   size_t r = e >> 6;
   const int w = (int)(r & 3); r >>= 2;
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(PackSplitArgs p
   const int blk = (int)(r / nst);
   const int co = blk * 128 + w * 32 + (lane & 31);
   const int c0 = st * 16 + 8 * (lane >> 5);
+  const float wscale = (S::SCALED && co < p.cout) ? p.co_scale[co] : 1.f;
   u32x4 o;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void pack_weights_split_kernel(PackSplitArgs p
 template <class S>
 inline size_t packed_split_frags(int cin, int cout, int taps = 9) { return (size_t)((cout + 127) / 128) * (cin / 16) * taps * S::NS * 4 * 64; }
 template <class S>
-inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<S>(cin, cout) * 16 + 16; }
+inline size_t packed_split_bytes(int cin, int cout, int taps = 9) { return packed_split_frags<S>(cin, cout, taps) * 16 + (size_t)((cout + 127) / 128) * 128 * 8; }
 
 // Workgroup shapes (all with the same K order, epilogue and per-row GroupNorm partials: bit-identical results):
 //   SHAPE 0: the four waves own the four 32-channel fragments of a 128-channel block, each all 8 pixel fragments
@@ -190,7 +196,7 @@ inline size_t packed_split_bytes(int cin, int cout) { return packed_split_frags<
 // correct results: 64 phase time stamps per workgroup (ConvArgs::trace), 128 / 256 epilogue variants (conv_epilogue), 512 LDS
 // padded to one workgroup per CU.
 // (a 2 x 4 register blocking of a wave -- two channel fragments x half of the pixel fragments, half the LDS operand reads --
-// measured the same as this 1 x 8 blocking, profiles/r02: gpu_r02_blk.sh; removed in round 4)
+// measured the same as this 1 x 8 blocking, profiles/r02_conv_microbench_kernel_families.txt; removed in round 4)
 // SC = 1: with the folded 1x1 residual shortcut (ConvArgs::sc_*): its K-stages run first on accumulators that start from
 // zero; the accumulators are then rescaled by the (exact, power-of-two) ratio of the two operand scalings, receive the
 // bias terms, and the 3x3 stages continue on top.
@@ -403,9 +409,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) init[r] = 0.f;
     } else {
-      const float inv = 1.0f / ((p.acc_scale ? *p.acc_scale : 1.0f) * inv_kx);
+      const int co_l = co_blk * T::CO_T + (wc * FCW + i) * 32 + 4 * kg;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) init[r] = acc_raw[i][r] * inv;
+      for (int r = 0; r < 16; ++r) init[r] = acc_raw[i][r] * (1.0f / (conv_as(p, co_l + (r & 3) + 8 * (r >> 2)) * inv_kx));      // (powers of two: exact)
     }
 #pragma unroll
     for (int j = 0; j < FPW; ++j)
@@ -540,19 +546,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       }
     }
     // accumulator: from the shortcut's operand scaling (weights 2^k1, input xs) to the 3x3 stages' (acc_scale), plus the biases
-    const float as3 = *p.acc_scale * inv_kx;
-    const float rho = (*p.sc_scale / xs) / as3;
 #pragma unroll
     for (int i = 0; i < FCW; ++i) {
-      float init[16];
+      float init[16], rho[16];
       conv_acc_init<T>(p, b, co_blk, wc * FCW + i, kg, inv_kx, init);
       const int co_l = co_blk * T::CO_T + (wc * FCW + i) * 32 + 4 * kg;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) init[r] += p.sc_bias ? p.sc_bias[co_l + (r & 3) + 8 * (r >> 2)] / as3 : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_l + (r & 3) + 8 * (r >> 2);
+        const float as3 = conv_as(p, co) * inv_kx;                 // per output channel: the two layers' weight scales are per channel
+        rho[r] = (p.sc_scale[co] / xs) / as3;
+        init[r] += p.sc_bias ? p.sc_bias[co] / as3 : 0.f;
+      }
 #pragma unroll
       for (int j = 0; j < FPW; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * rho + init[r];
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * rho[r] + init[r];
     }
   }
   // prologue: first stage -> s_in0 (its raw loads were issued at the top; behind a folded shortcut they are issued here)
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   // traffic each ADDED their time to the K loop).  9 taps % 3 == 0: the ring index of a tap is the same in every stage.
   unsigned long long tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // ABL 64: time per tap position and at the stage barrier (wave 0)
   // (a ring holding a whole stage -- 9 sets, 8 taps ahead -- for the 4-row shape, whose taps have half the MFMAs to cover a
-  // load, measured no gain at batch 1 and costs the third workgroup per CU: profiles/r02 gpu_r02_coarse.sh)
+  // load, measured no gain at batch 1 and costs the third workgroup per CU: profiles/r02_chunk_splitk.txt)
   if constexpr (THIN && !ABL) {
     // ---- thin shape (C -> 4 pyramid convolutions): a tap is only 6 MFMAs per wave (~190 cycles), so the fragment ring above (two
     // taps of cover, and vmcnt retires in order: a fragment wait also waits for the raw HBM loads issued in front of it) is
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
       thin_stage(st, s_in0, s_in1, rin);
       if (st + 1 < nst) thin_stage(st + 1, s_in1, s_in0, rin2);
     }
-    conv_epilogue<T, FCW, FPW, WCW, 0, true, false>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
+    conv_epilogue<T, FCW, FPW, WCW, 0, true, false, S::SCALED>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
       return;
   }
   constexpr int AR = 3, AD = AR - 1;
@@ -684,7 +693,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
     } else {                                        // raw partial sums of this chunk; the reduce kernel runs the epilogue
       ConvArgs q = p;
       q.out = p.partial + (size_t)blockIdx.z * conv_partial_slab(p, H, W);
-      q.bias = nullptr; q.bias2 = nullptr; q.res = nullptr; q.acc_scale = nullptr; q.out_scale = 1.f; q.stats_out = nullptr; q.amax_out = nullptr;
+      q.bias = nullptr; q.bias2 = nullptr; q.res = nullptr; q.acc_scale = nullptr; q.co_scale = nullptr; q.out_scale = 1.f; q.stats_out = nullptr; q.amax_out = nullptr;
       conv_epilogue<T, FCW, FPW, WCW, 0, true>(q, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg);
       // (conv_splitk_reduce_kernel follows)
       return;
@@ -698,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(ConvArgs p) {
   }
 
   if constexpr (ABL & 64) { if (trace) trace[3] = drt_clock(); }
-  conv_epilogue<T, FCW, FPW, WCW, ABL & (3 | 128 | 256), !CHK, FPW % 4 == 0>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
+  conv_epilogue<T, FCW, FPW, WCW, ABL & (3 | 128 | 256), !CHK, FPW % 4 == 0, S::SCALED>(p, acc, b, co_blk, tx, ty, tiles_x, wc, wp, l31, kg, inv_kx);
   if constexpr (ABL & 64) { if (trace) trace[4] = drt_clock(); }
 }
 
@@ -859,7 +868,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(ConvArgs p) {
       for (int e = 0; e < 8; ++e) rinA[i][e] = rinB[i][e];
   }
 
-  conv_epilogue<T, 1, 8, 4, 0, false, true>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg, 1.0f / xs);
+  conv_epilogue<T, 1, 8, 4, 0, false, true, S::SCALED>(p, acc, b, co_blk, tx, ty, tiles_x, wave, 0, l31, kg, 1.0f / xs);
 }
 
 }  // namespace sgmse

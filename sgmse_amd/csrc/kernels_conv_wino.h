@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float as3 = cs_inv[r] * inv_kx;
-      const float rho = (*p.sc_scale / xs) / as3;
+      const float rho = (p.sc_scale[co_blk * 128 + cf * 32 + 4 * kg + (r & 3) + 8 * (r >> 2)] / xs) / as3;      // (the 1x1 layer's scale is per channel too)
       const int co = co_blk * 128 + cf * 32 + 4 * kg + (r & 3) + 8 * (r >> 2);
       const float add = sgn * (acc_raw[r] + (p.sc_bias ? p.sc_bias[co < p.Cout ? co : 0] : 0.f)) / as3;
       if (kh == 0) {
@@ -535,13 +535,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   constexpr bool ALL_TO_A = ROWS == 4;
   const bool fin_wave = !ALL_TO_A || kh == 0;
   const int ef0 = ALL_TO_A ? 0 : 2 * kh;                   // first fragment this wave finishes
-  const int pos_row = l31 >> 4, m2 = 2 * (l31 & 15);
+  // (the lane's coordinates derived afresh from the thread id: kept alive across the K loop from the prologue they were spilled)
+  int tid_e = (int)threadIdx.x;
+  DRT_PIN_INT(tid_e);
+  const int lane_e = tid_e & 63, l31_e = lane_e & 31, kg_e = lane_e >> 5;
+  const int pos_row = l31_e >> 4, m2 = 2 * (l31_e & 15);
   const int yb = y0 + 2 * ef0 + pos_row, x = x0 + m2;      // row of fragment slot 0, first column of the pair
   const bool okc = x < W;
   const bool inside = x0 + 32 <= W && y0 + ROWS <= H;      // workgroup-uniform: no access of the tile needs a guard
   const size_t ubase = (size_t)b * p.Cout * HW;
-  const int co_l = co_blk * 128 + cf * 32 + 4 * kg;        // + (r & 3) + 8 (r >> 2)
-  // byte offset of fragment slot f of this lane inside the utterance (clamped into the image: guarded accesses never use the value)
+  const int co_l = co_blk * 128 + cf * 32 + 4 * kg_e;        // + (r & 3) + 8 (r >> 2)
+  // byte offset of fragment slot f of this lane_e inside the utterance (clamped into the image: guarded accesses never use the value)
   unsigned lane_boff[EF];
 #pragma unroll
   for (int f = 0; f < EF; ++f) {
@@ -564,9 +568,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   }
   if constexpr (TRACE) { if (trace) trace[7] = drt_clock() - trace[3]; }       // residual loads issued
   {
-    // exchange slots: [channel fragment][direction: 0 = for the A-wave, 1 = for the B-wave][fragment slot][register][lane] float2
+    // exchange slots: [channel fragment][direction: 0 = for the A-wave, 1 = for the B-wave][fragment slot][register][lane_e] float2
     float2* xs = reinterpret_cast<float2*>(s_all);
-    auto slot = [&](int dir, int f, int r) -> float2* { return xs + ((((cf * G::NDIR + dir) * EF + f) * 16 + r) * 64 + lane); };
+    auto slot = [&](int dir, int f, int r) -> float2* { return xs + ((((cf * G::NDIR + dir) * EF + f) * 16 + r) * 64 + lane_e); };
     if (kh == 0) {
       if constexpr (!ALL_TO_A) {
 #pragma unroll
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
     }
     if constexpr (TRACE) { if (trace) trace[10] = drt_clock() - trace[3]; }    // outputs stored (issued)
     if (p.stats_out && y0 + 2 * ef0 < H) {
-      // {sum, sum of squares} of the wave's 4-row x 32-column sub-tile per channel: the 16 per-lane sums of each kind through one
+      // {sum, sum of squares} of the wave's 4-row x 32-column sub-tile per channel: the 16 per-lane_e sums of each kind through one
       // exchange-add butterfly over the 32 lanes of a half wave (as conv_epilogue, once per wave instead of once per row)
       auto butterfly = [&](float (&sv)[16]) -> float {
         float a[8];
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
       const float e2 = butterfly(s2);
       __builtin_amdgcn_sched_barrier(0);
       const float e1 = butterfly(s1);
-      const int r = ((l31 >> 4) & 1) * 8 + ((l31 >> 3) & 1) * 4 + ((l31 >> 2) & 1) * 2 + (l31 & 1);
+      const int r = ((l31_e >> 4) & 1) * 8 + ((l31_e >> 3) & 1) * 4 + ((l31_e >> 2) & 1) * 2 + (l31_e & 1);
       const int co = co_l + (r & 3) + 8 * (r >> 2);
       float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)((y0 + 2 * ef0) >> 2) * tiles_x + tx) * 2;
       so[0] = e1; so[1] = e2;
@@ -655,7 +659,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
     if (p.amax_out) {
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-      if (lane == 0) drt_atomic_max_nonneg(p.amax_out + b * kAmaxSpread + ((blockIdx.x * 8 + wave) & (kAmaxSpread - 1)), vmax);
+      if (lane_e == 0) drt_atomic_max_nonneg(p.amax_out + b * kAmaxSpread + ((blockIdx.x * 8 + wave) & (kAmaxSpread - 1)), vmax);
     }
     DRT_CODE_MARKER(GUARD);
   };

@@ -131,6 +131,7 @@ __device__ __forceinline__ int drt_uniform(int v) { return __builtin_amdgcn_read
 // executes its LDS operations in order, so this only pins the compiler's ordering (the emulator synchronises its fibers)
 __device__ __forceinline__ void drt_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #define DRT_PIN_HERE(x) asm volatile("" : "+v"(x))
+#define DRT_PIN_INT(x) asm volatile("" : "+v"(x))
 #define DRT_CODE_MARKER(n) asm volatile("; code marker %0" ::"n"(n))
 #define DRT_LAUNCH(kern, grid, block, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)

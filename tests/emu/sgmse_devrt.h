@@ -144,6 +144,7 @@ static inline double drt_shfl_xor_f64(double v, int mask) {
 
 static inline void drt_wave_sync() { (void)emu::shfl_idx(0.f, 0); }
 #define DRT_PIN_HERE(x) ((void)0)
+#define DRT_PIN_INT(x) ((void)0)
 #define DRT_CODE_MARKER(n) ((void)0)
 #define DRT_LAUNCH(kern, grid, block, stream, ...) \
   do { (void)(stream); emu::launch((grid), (block), [=]() { kern(__VA_ARGS__); }); } while (0)

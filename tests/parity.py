@@ -318,7 +318,10 @@ def adversarial_params(cfg, kind, seed=0):
       gn_wild     gamma up to 8 everywhere, single channels at 30, beta up to 500
       growth      residual stream growing ~10^3 across the network (Conv_1 and the shortcut of every block scaled up)
       outliers    a few output channels of some convolutions x 10^4 (heavy-tailed activations)
-      zero_init   Conv_1 of every block at the reference's init_scale=0 magnitude (1e-10, layers.py:88-91): dead branches"""
+      zero_init   Conv_1 of every block at the reference's init_scale=0 magnitude (1e-10, layers.py:88-91): dead branches
+      single_weights  single weights x 10^6 in Conv_0 (x 10^3 in Conv_1 and the 1x1 shortcut) of every third block: the fp16x2
+                  weight scales are per OUTPUT CHANNEL, so the other channels of the layer keep their low
+                  bits (a per-layer scale would push them 2^20 down into fp16 subnormals)"""
     P = synth.synth_params(cfg, seed=seed)
     g = torch.Generator().manual_seed(seed + 101)
     res_blocks = sorted({k.rsplit(".", 2)[0] for k in P if k.endswith("Conv_1.weight")}, key=lambda n: int(n.split(".")[1]))
@@ -350,6 +353,16 @@ def adversarial_params(cfg, kind, seed=0):
             P[name + ".Conv_1.weight"][:3] *= 1e4
             P[name + ".Conv_0.weight"][5:7] *= 1e4
         P["all_modules.3.weight"][:2] *= 1e4
+    elif kind == "single_weights":
+        # (in Conv_0 only: its output is normalised by GroupNorm_1.  The same factor in Conv_1 / the shortcut lands on the residual
+        #  stream, which nothing normalises, and overflows the REFERENCE's own fp32 arithmetic a few blocks later; those two get 10^3.)
+        for i, name in enumerate(res_blocks[::3]):
+            w0, w1 = P[name + ".Conv_0.weight"], P[name + ".Conv_1.weight"]
+            w0[1 + i % 5, i % w0.shape[1], 1, 1] *= 1e6
+            w0[64 + i % 7, (3 + i) % w0.shape[1], 0, 2] *= 1e6
+            w1[2 + i % 7, (3 + i) % w1.shape[1], 0, 2] *= 1e3
+            if name + ".Conv_2.weight" in P:
+                P[name + ".Conv_2.weight"][i % 4, 1 + i % 3, 0, 0] *= 1e3
     elif kind == "zero_init":
         for name in res_blocks:
             P[name + ".Conv_1.weight"] *= 1e-10

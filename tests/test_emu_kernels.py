@@ -244,6 +244,12 @@ def test_adversarial_checkpoint_wild_groupnorm_parameters(emu):
     P.check_adversarial_checkpoint(emu, "gn_wild", nf=32, expect_mode=2)
 
 
+@pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get("SGMSE_SLOW"), reason="full-width network on the emulator (minutes); set SGMSE_SLOW=1")
+def test_adversarial_checkpoint_single_weights_times_a_million(emu):
+    P.check_adversarial_checkpoint(emu, "single_weights", nf=128, expect_mode=2)
+
+
 def test_adversarial_checkpoint_residual_stream_growth(emu):
     P.check_adversarial_checkpoint(emu, "growth", nf=32, expect_mode=2)
 

@@ -344,10 +344,10 @@ def test_batch_of_four_equals_four_singles_bitwise(hip):
     P.check_batch_equals_singles(hip, 4)
 
 
-@pytest.mark.parametrize("kind", ["gn_inside", "gn_outside", "gn_wild", "growth", "outliers", "zero_init"])
+@pytest.mark.parametrize("kind", ["gn_inside", "gn_outside", "gn_wild", "growth", "outliers", "single_weights", "zero_init"])
 def test_adversarial_checkpoints_keep_the_network_gate(hip, kind):
     """Full-width network at the bench shape (T = 512) with synthetic state dicts built to stress the fp16x2 range handling
-    (GroupNorm parameters far beyond any worst-case guard, a residual stream growing 10^3, outlier channels x 10^4, dead Conv_1
+    (GroupNorm parameters far beyond any worst-case guard, a residual stream growing 10^3, outlier channels x 10^4, single weights x 10^6, dead Conv_1
     branches) against the oracle: the per-utterance data-driven input scale keeps the fast kernel family (mode 2) every time."""
     P.check_adversarial_checkpoint(hip, kind, T=512, expect_mode=2)
 

@@ -78,16 +78,28 @@ if has rocprof; then
   rm -rf $O/prof
 fi
 if has pmc; then
+  rm -rf $O/pmc; mkdir -p $O/pmc
   # counters of the dominant kernel on its micro-benchmark, one pass per counter group (the guide's HBM recipe: FETCH_SIZE and
   # WRITE_SIZE in separate passes, calibrated on a float4 stream of known size in the same run)
   echo "== PMC passes (PMC_VARIANT=${PMC_VARIANT:-1152})"
-  for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "FETCH_SIZE" "WRITE_SIZE"; do
-    n=$(echo $grp | tr ' ' '_' | cut -c1-40)
-    rm -rf $O/pmc_$n
-    VARIANTS=${PMC_VARIANT:-1152} SHAPES=${PMC_SHAPES:-0} FUSED=1 ROUNDS=1 CALIB=1 OUT=${TAG}_pmc_microbench.json timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_$n -o pmc -- python tools/conv_microbench.py > $O/pmc_$n.log 2>&1
-    echo "pmc [$grp] rc=$?"
+  i=0
+  for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i + 1)); n=$(echo $grp | cut -d' ' -f1)
+    VARIANTS=${PMC_VARIANTS:-128,1152} SHAPES=${PMC_SHAPES:-0} FUSED=1 ROUNDS=1 CALIB=1 OUT=${TAG}_pmc_microbench.json timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc/$n -o pmc -- python tools/conv_microbench.py > $O/pmc/$n.log 2>&1
+    echo "pmc pass $i [$grp] rc=$?"
   done
-  python tools/summarize_pmc.py $O ${TAG} 2>&1 | tail -30
+  python tools/summarize_pmc.py $O/pmc/SQ_VALU_MFMA_BUSY_CYCLES $O/pmc/SQ_INSTS_VALU $O/pmc/SQ_LDS_BANK_CONFLICT > $O/${TAG}_pmc_conv.json 2>$O/pmc/summ.err
+  python tools/summarize_hbm.py $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE $O/${TAG}_pmc_microbench.json > $O/${TAG}_hbm_traffic.json 2>>$O/pmc/summ.err
+  python - <<PY
+import json
+for f in ("$O/${TAG}_pmc_conv.json", "$O/${TAG}_hbm_traffic.json"):
+    try:
+        d = json.load(open(f))
+        for k, v in d.items():
+            if "conv3x3" in k: print(f.split("/")[-1], k[:90], {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items() if a != "counters_mean"})
+    except Exception as e: print(f, "FAILED", e)
+PY
+  rm -rf $O/pmc/*/ 2>/dev/null
 fi
 if has dumps; then
   echo "== per-launch timings of one evaluation (batch 32 and batch 1)"
