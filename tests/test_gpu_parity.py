@@ -332,7 +332,7 @@ def test_full_width_48k_forward_at_the_benched_shape_against_oracle(hip):
     assert err < P.NET_TOL
 
 
-@pytest.mark.parametrize("name", ["pc16k_full", "ode16k_full", "pc48k_full", "pc48k_T512"])
+@pytest.mark.parametrize("name", ["pc16k_full", "ode16k_full", "pc48k_full", "pc48k_T512", "pc48k_T512_N50"])
 def test_baseline_configuration_end_to_end_against_the_reference(hip, name):
     """BASELINE.json configs[0]/[1] (PC N=30), configs[2] (PF-ODE N=30) and configs[3] (48 kHz, PC N=50) at full width,
     full length and full N: sampled spectrogram and enhanced waveform vs the reference's own run (tests/golden/*_full.npz);
