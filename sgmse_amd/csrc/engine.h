@@ -668,11 +668,9 @@ class Engine {
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
     SG_REQUIRE(pl.mfma, "bench_conv: shape is not MFMA-eligible");
     if (variant >= 0 && (variant & 512)) { pl.rows = 4; variant &= ~512; }   // measurement knob: 128 co x 128 px tile
-    int ablate = 0, abl_split = 0, stag = -1, stag_mode = 0;
+    int ablate = 0, abl_split = 0;
     bool split_rows4 = false;
     if (variant >= 0) {
-      stag = (variant >> 24) & 127;              // measurement knob: start-up stagger of the Winograd kernel, sleep units per phase step
-      stag_mode = (variant >> 22) & 1;
       split_rows4 = (variant >> 23) & 1;         // measurement knob: 4-row workgroup shape of the split 3x3 kernel
       abl_split = (variant >> 12) & 1023;        // measurement knob: compile-time variant of the split 3x3 kernel, bits 12..21
       if (!(variant & (64 | 128))) { ablate = abl_split & 15; abl_split = 0; }   // fp32 kernels: run-time ablation bits 12..15
@@ -723,8 +721,6 @@ class Engine {
       bounds = input_bounds(x, Cin, nullptr, 0, B, H * W);
       xbound = producer_bound(a.in_scale, a.in_shift, Cin, bounds, nullptr, B); a.xbound = xbound;
     }
-    a.stagger = stag > 0 ? stag : 0;
-    (void)stag_mode;
     unsigned long long* trace_dev = nullptr;
     const size_t n_wg = (size_t)B * ((H + 7) / 8) * ((W + 31) / 32) * ((Cout + 127) / 128);
     if (abl_split & 64) {

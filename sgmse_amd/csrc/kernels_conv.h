@@ -47,7 +47,6 @@ struct ConvArgs {
   int in_act;              // 1: SiLU after the affine
   const float* res;        // residual [B][Cout][H][W] or null
   const float* acc_scale;  // device scalar multiplying the accumulator first (split kernels with pre-scaled operands), or null
-  int stagger;             // conv3x3_wino_kernel: start-up de-phasing of the first residency round, sleep units per phase step (0: off)
   const float* co_scale;   // conv3x3_wino_kernel: per OUTPUT CHANNEL factor undoing the weights' power-of-two scale ([ceil(Cout/128)*128])
   float out_scale;         // out = (acc * acc_scale + bias + bias2 + res) * out_scale
   float* out;

@@ -149,17 +149,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
       trace[1] = drt_clock();
     }
   }
-  // One workgroup owns a CU and every workgroup of a launch takes the same time: left alone, all 256 CUs stream their K loops and
-  // then their epilogues in lock step -- HBM idles during the loops and is saturated by 256 simultaneous residual reads + output
-  // writes behind them.  The workgroups of the FIRST residency round (one per CU) start phase * stagger sleep units late, phase in
-  // 0..15 scattered over the CUs; the rounds that follow inherit the offsets.
-  if (p.stagger > 0) {
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-    if (lin < 256u) {
-      const unsigned ph = (lin * 2654435761u) >> 28;
-      for (unsigned i = 0; i < ph * (unsigned)p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
+  // (One workgroup owns a CU and every workgroup of a launch takes the same time, so all 256 CUs run their K loops and then their
+  //  epilogues in lock step.  De-phasing the first residency round by up to a tile time did not shorten the epilogue -- it is bound by
+  //  the CU's own vector-memory issue rate, ~25 cycles per wave instruction, not by the simultaneous burst -- and cost its start-up
+  //  delay: profiles/r04_wino_microbench_history.txt visit r04b, r04_wino_trace.txt; removed.)
   const int Cin = p.C1 + p.C2;
   const int tiles_xg = (p.W + 31) >> 5;
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
