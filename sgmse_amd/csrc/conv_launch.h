@@ -5,6 +5,7 @@
 #include "kernels_conv1x1.h"
 #include "kernels_conv_split.h"
 #include "kernels_conv_wino.h"
+#include "kernels_conv_thin.h"
 
 #ifndef SGMSE_CONV_SPLIT_DEFAULT
 #define SGMSE_CONV_SPLIT_DEFAULT 2     // 0: fp32 MFMA everywhere, 1: bf16x3 on the wide levels, 2: fp16x2 on the wide levels
@@ -185,6 +186,13 @@ inline void launch_conv_wino(const ConvArgs& a, drt::stream_t st, bool rows4, bo
     else if (act) DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0>), grid, dim3(512), st, a);
     else DRT_LAUNCH((conv3x3_wino_kernel<8, 0, 0>), grid, dim3(512), st, a);
   }
+}
+
+// exact-fp32 VALU kernel of the C -> 4 pyramid convolutions (kernels_conv_thin.h); a.w = OIHW weights
+inline void launch_conv_thin(const ConvArgs& a, drt::stream_t st) {
+  const dim3 grid(conv_thin_grid_tiles(a, (a.W + ConvThinGeom::TW - 1) / ConvThinGeom::TW), 1, 1);
+  if (a.in_scale && a.in_act) DRT_LAUNCH((conv3x3_thin_kernel<1>), grid, dim3(256), st, a);
+  else DRT_LAUNCH((conv3x3_thin_kernel<0>), grid, dim3(256), st, a);
 }
 
 inline void launch_conv_direct(const ConvArgs& a, int ks, drt::stream_t st) {

@@ -548,7 +548,11 @@ class Engine {
     a.src1 = x; a.src2 = x2; a.C1 = Cin - C2; a.C2 = C2; a.bias = bias; a.res = res; a.out_scale = out_scale; a.out = out;
     a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
-    if (force_direct == 4 || force_direct == 5) {          // Winograd F(2,3) x fp16x2: 4 = 8-row shape, 5 = 4-row shape
+    if (force_direct == 6) {                               // exact-fp32 VALU kernel of the C -> 4 pyramid convolutions
+      SG_REQUIRE(conv_thin_eligible(ks, a.C1, C2, Cout), "op_conv2d: shape is not eligible for the thin-output kernel");
+      a.w = w_oihw;
+      launch_conv_thin(a, stream_);
+    } else if (force_direct == 4 || force_direct == 5) {          // Winograd F(2,3) x fp16x2: 4 = 8-row shape, 5 = 4-row shape
       SG_REQUIRE(ks == 3 && conv_wino_eligible(a.C1, C2, Cout, W), "op_conv2d: shape is not eligible for the Winograd kernel");
       const float* pk = pack_wino(w_oihw, Cin, Cout, false, &a.co_scale);
       a.w = pk;
@@ -1356,7 +1360,16 @@ class Engine {
       ca.sc_amax1 = sc->a->amax; ca.sc_amax2 = sc->b ? sc->b->amax : nullptr;
       fl += 2.0 * B_ * (double)w.cout * Cs * a.H * a.W;
     }
-    if (use_split) {
+    // the C -> 4 convolutions of the output pyramid: exact-fp32 VALU kernel (kernels_conv_thin.h) at every level -- on the matrix pipe
+    // seven eighths of their work was padding (decided by the layer's shape alone: never by batch, level or utterance length)
+    const bool use_thin = conv_thin_eligible(w.ks, a.C, b ? b->C : 0, w.cout) && !emit_stats;
+    if (use_thin) {
+      ca.w = w.oihw; ca.stats_out = nullptr;
+      launch_conv_thin(ca, stream_);
+      if (noting()) snprintf(prof_note_, sizeof prof_note_, "conv3x3-thin %d->%d @%dx%dx%d%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "");
+      tick(TC_CONV3, fl);
+      if (partial) arena_.release(partial);
+    } else if (use_split) {
       ca.w = w.packed_split; ca.co_scale = w.split_scale;      // (null for bf16x3: no scale)
       if (w.ks == 1 && w.split_mode == 2) { ca.amax1 = a.amax; ca.amax2 = b ? b->amax : nullptr; }
       if (w.ks == 3 && w.split_mode == 2) ca.xbound = xf.bound;

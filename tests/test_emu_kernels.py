@@ -73,6 +73,15 @@ def test_conv3x3_winograd_fp16x2_kernel_has_fp32_accuracy(emu):
     P.check_conv_wino(emu, 1, 32, 128, 8, 32, wmul=6)
 
 
+def test_conv3x3_thin_output_valu_kernel(emu):
+    """C -> 4 pyramid convolutions on the exact-fp32 VALU kernel (kernels_conv_thin.h; the engine's path for these layers): fp32
+    accuracy against float64 (no worse than 1.5x the fp32 MFMA kernel's own error), ragged tile edges, 2 output channels, dual input."""
+    P.check_conv_b3(emu, 1, 64, 4, 9, 33, xform=True, split="thin", slack=1.5)
+    P.check_conv_b3(emu, 2, 128, 4, 20, 70, xform=True, split="thin", slack=1.5)
+    P.check_conv_b3(emu, 1, 64, 2, 17, 128, xform=False, split="thin", slack=1.5)
+    P.check_conv_b3(emu, 1, 96, 4, 5, 32, dual=32, xform=True, split="thin", slack=1.5)
+
+
 def test_conv3x3_thin_output_split_kernel(emu):
     """C -> 4 pyramid convolutions on the split kernel's thin variant (one padded 32-channel fragment, waves split pixels)."""
     P.check_conv_b3(emu, 1, 64, 4, 9, 33, xform=True, split="fp16x2", slack=3.0)

@@ -81,6 +81,15 @@ def test_conv3x3_bf16x3_kernel_has_fp32_accuracy(hip):
     P.check_conv_b3(hip, 1, 512, 256, 16, 32, dual=256, xform=True)
 
 
+def test_conv3x3_thin_output_valu_kernel(hip):
+    """C -> 4 pyramid convolutions on the exact-fp32 VALU kernel (kernels_conv_thin.h; the engine's path for these layers): fp32
+    accuracy against float64 (no worse than 1.5x the fp32 MFMA kernel's own error), ragged tile edges, 2 output channels, dual input."""
+    P.check_conv_b3(hip, 1, 64, 4, 9, 33, xform=True, split="thin", slack=1.5)
+    P.check_conv_b3(hip, 2, 128, 4, 20, 70, xform=True, split="thin", slack=1.5)
+    P.check_conv_b3(hip, 1, 64, 2, 17, 128, xform=False, split="thin", slack=1.5)
+    P.check_conv_b3(hip, 1, 96, 4, 5, 32, dual=32, xform=True, split="thin", slack=1.5)
+
+
 def test_conv3x3_thin_output_split_kernel(hip):
     """C -> 4 pyramid convolutions on the split kernel's thin variant (one padded 32-channel fragment, waves split pixels)."""
     P.check_conv_b3(hip, 1, 64, 4, 9, 33, xform=True, split="fp16x2", slack=3.0)
