@@ -188,7 +188,7 @@ inline void launch_conv_wino(const ConvArgs& a, drt::stream_t st, bool rows4, bo
   }
 }
 
-// exact-fp32 VALU kernel of the C -> 4 pyramid convolutions (kernels_conv_thin.h); a.w = OIHW weights
+// exact-fp32 VALU kernel of the C -> 4 pyramid convolutions (kernels_conv_thin.h); a.w = weights packed by pack_weights_thin_kernel
 inline void launch_conv_thin(const ConvArgs& a, drt::stream_t st) {
   const dim3 grid(conv_thin_grid_tiles(a, (a.W + ConvThinGeom::TW - 1) / ConvThinGeom::TW), 1, 1);
   if (a.in_scale && a.in_act) DRT_LAUNCH((conv3x3_thin_kernel<1>), grid, dim3(256), st, a);

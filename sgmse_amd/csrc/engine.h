@@ -248,6 +248,7 @@ struct ConvW {            // one convolution's parameters on the device
   const float* packed = nullptr; // MFMA layout (null if the shape is not MFMA-eligible)
   const float* packed32 = nullptr; // second MFMA layout with 32-channel output tiles: 4x more workgroups for launches that
                                    // would otherwise leave most CUs idle (the 16x32 ... 4x8 levels of the U-Net)
+  const float* packed_thin = nullptr;  // [ci][tap][4 co] of the C -> 4 layers (kernels_conv_thin.h)
   const float* packed_split = nullptr; // split-kernel fragment layout (kernels_conv_split.h) in the engine's split mode,
                                        // 3x3 with cout % 128 == 0, cin % 16 == 0
   const float* split_scale = nullptr;  // fp16x2: per output channel the factor undoing its weights' power-of-two scale (table behind the fragments)
@@ -550,7 +551,7 @@ class Engine {
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
     if (force_direct == 6) {                               // exact-fp32 VALU kernel of the C -> 4 pyramid convolutions
       SG_REQUIRE(conv_thin_eligible(ks, a.C1, C2, Cout), "op_conv2d: shape is not eligible for the thin-output kernel");
-      a.w = w_oihw;
+      a.w = pack_thin(w_oihw, Cin, Cout, false);
       launch_conv_thin(a, stream_);
     } else if (force_direct == 4 || force_direct == 5) {          // Winograd F(2,3) x fp16x2: 4 = 8-row shape, 5 = 4-row shape
       SG_REQUIRE(ks == 3 && conv_wino_eligible(a.C1, C2, Cout, W), "op_conv2d: shape is not eligible for the Winograd kernel");
@@ -894,6 +895,7 @@ class Engine {
       c.split_mode = split_mode_;
       c.packed_split = pack_split(c.oihw, ks, cin, cout, c.split_mode, true, &c.split_scale);
     }
+    if (conv_thin_eligible(ks, cin, 0, cout)) c.packed_thin = pack_thin(c.oihw, cin, cout, true);
     // the wide levels run these layers on the Winograd F(2,3) x fp16x2 kernel (conv(): use_wino)
     if (split_mode_ == 2 && wino_ && ks == 3 && conv_wino_eligible(cin, 0, cout, 2)) c.packed_wino = pack_wino(c.oihw, cin, cout, true, &c.wino_scale);
     return c;
@@ -923,6 +925,12 @@ class Engine {
   }
 
   // weights in the fragment order of conv3x3_wino_kernel: transformed along the kernel's columns in fp64, scaled per output channel
+  const float* pack_thin(const float* oihw, int cin, int cout, bool weight_owned) {
+    const size_t ne = packed_thin_elems(cin);
+    float* pk = static_cast<float*>(weight_owned ? dev_alloc_w(ne * 4) : dev_alloc_tmp(ne * 4));
+    DRT_LAUNCH(pack_weights_thin_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, oihw, pk, cin, cout);
+    return pk;
+  }
   const float* pack_wino(const float* oihw, int cin, int cout, bool weight_owned, const float** scale_out) {
     const size_t frags = packed_wino_frags(cin, cout);
     const int cout_pad = (cout + 127) / 128 * 128;
@@ -1268,14 +1276,15 @@ class Engine {
     // its results differ from the fp32-MFMA kernels in the last bits and an utterance must not depend on its batch.
     const int Wd = dec_W(a.H);          // family decisions by the level, not by the utterance length (see dec_W)
     const long tiles8 = (long)((a.H + 7) / 8) * ((Wd + 31) / 32);
-    // Levels with 2..chunk_max_tiles_ tiles per nominal image (16 x 32, 32 x 64): the fp16x2 split kernel in its 4-row shape with CHUNKED
-    // accumulation, so that a small batch can spread the chunks over workgroups (split-K, bit-identical) instead of running 16-32
+    // Levels with at most chunk_max_tiles_ tiles per nominal image (32 x 64 and below): the fp16x2 split kernel in its 4-row shape with
+    // CHUNKED accumulation, so that a small batch can spread the chunks over workgroups (split-K, bit-identical) instead of running 16-32
     // serial stages on 8-32 workgroups; full 3x3 blocks behind a GroupNorm producer only (not the launches with a folded
     // shortcut).  Decided per layer and level, never by the batch or the utterance length: chunking fixes the summation order.
+    // The 8 x 16 and 4 x 8 levels joined in round 4: their tiles are half / three quarters empty, yet at batch 32 the layers take 0.057 /
+    // 0.038 ms against 0.115 / 0.065 ms on the fp32 kernels (+1.7 % utterances/s); a single utterance pays 9 us per layer for the
+    // four times wider output tile of a workgroup (434 -> 452 ms per utterance at batch 1; profiles/r04_coarse_levels.txt).
     const bool coarse_split = coarse_split_ && use_mfma && w.packed_split && w.split_mode == 2 && w.ks == 3 && w.cout > 32 && !sc &&
-                              conv_split_eligible(3, a.C, b ? b->C : 0, w.cout) && tiles8 >= chunk_min_tiles_ && tiles8 <= chunk_max_tiles_ &&
-                              Wd >= chunk_min_width_ &&
-                              xf.bound != nullptr;
+                              conv_split_eligible(3, a.C, b ? b->C : 0, w.cout) && tiles8 <= chunk_max_tiles_ && xf.bound != nullptr;
     const bool use_split = coarse_split || (use_mfma && w.packed_split &&
                         (conv_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout) || conv_thin_split_eligible(w.ks, a.C, b ? b->C : 0, w.cout)) &&
                         tiles8 >= split_min_tiles_ &&
@@ -1360,11 +1369,12 @@ class Engine {
       ca.sc_amax1 = sc->a->amax; ca.sc_amax2 = sc->b ? sc->b->amax : nullptr;
       fl += 2.0 * B_ * (double)w.cout * Cs * a.H * a.W;
     }
-    // the C -> 4 convolutions of the output pyramid: exact-fp32 VALU kernel (kernels_conv_thin.h) at every level -- on the matrix pipe
-    // seven eighths of their work was padding (decided by the layer's shape alone: never by batch, level or utterance length)
-    const bool use_thin = conv_thin_eligible(w.ks, a.C, b ? b->C : 0, w.cout) && !emit_stats;
+    // the C -> 4 convolutions of the output pyramid: exact-fp32 VALU kernel (kernels_conv_thin.h) -- on the matrix pipe
+    // seven eighths of their work was padding (decided by the layer's shape and U-Net level alone: never by batch or utterance length)
+    // (the two finest levels: below them a launch at batch 1 has few 16 x 64 tiles and their 32-64 serial stages are slower than the MFMA path's split-K)
+    const bool use_thin = w.packed_thin && conv_thin_eligible(w.ks, a.C, b ? b->C : 0, w.cout) && !emit_stats && level_of(a.H) <= 1;
     if (use_thin) {
-      ca.w = w.oihw; ca.stats_out = nullptr;
+      ca.w = w.packed_thin; ca.stats_out = nullptr;
       launch_conv_thin(ca, stream_);
       if (noting()) snprintf(prof_note_, sizeof prof_note_, "conv3x3-thin %d->%d @%dx%dx%d%s%s", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "", xf.scale ? " +gn" : "");
       tick(TC_CONV3, fl);
@@ -1769,8 +1779,7 @@ class Engine {
   ConvW entry8_{}; int entry8_idx_ = -1;
   bool poison_ = false, debug_sync_ = false, conv_xcd_map_ = true, rag_prefix_ = true, wino_ = true;
   long wino_min_tiles_ = 32;
-  static constexpr long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8, chunk_min_tiles_ = 2;      // (profiles/r02_chunk_splitk.txt)
-  static constexpr int chunk_min_width_ = 32;
+  static constexpr long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8;      // (profiles/r02_chunk_splitk.txt)
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;
   char prof_note_[160] = {0};

@@ -6,7 +6,9 @@
 // eighths of the matrix work is padding.  On the vector ALU there is no padding: 4 co x 9 taps = 36 FMAs per input value, 19.3 GFMA for the
 // full-resolution launch at batch 32 against 131 TFMA/s of fp32 FMA on the chip.  The kernel is bound by those FMAs and by the LDS reads
 // that feed them, so each thread computes 4 neighbouring pixels (one 16-byte + one 8-byte LDS read per tile row and channel feed
-// 4 px x 3 taps) and all 4 output channels (16 accumulators); the weights are wave-uniform and come through the scalar cache.
+// 4 px x 3 taps) and all 4 output channels (16 accumulators); the weights (packed [ci][tap][4 co]) are staged through LDS with the tile
+// and read as wave-uniform broadcasts.  (Through the scalar cache instead -- s_load one step ahead -- every step waited on lgkmcnt(0),
+// which scalar loads force: 8.4 k cycles per 4-channel stage with one wave per SIMD, profiles/r04_thin_kernel.txt.)
 //
 //   workgroup = 256 threads = 16 rows x 64 columns of one utterance (thread: row t / 16, columns 4 (t % 16) .. + 3), 3 per CU;
 //   the FMAs are packed over output-channel pairs (v_pk_fma_f32: weight pair from SGPRs, the input value broadcast to both halves);
@@ -31,12 +33,21 @@ struct ConvThinGeom {
 inline bool conv_thin_eligible(int ks, int C1, int C2, int Cout) {
   return ks == 3 && Cout <= 4 && (C1 + C2) % ConvThinGeom::KC == 0 && (C2 == 0 || C1 % ConvThinGeom::KC == 0) && (C1 + C2) <= 512;
 }
+inline size_t packed_thin_elems(int Cin) { return (size_t)Cin * 36; }
+// OIHW -> [ci][tap][4 co] (output channels beyond Cout are zero)
+__global__ void pack_weights_thin_kernel(const float* __restrict__ oihw, float* __restrict__ dst, int Cin, int Cout) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Cin * 36) return;
+  const int co = e & 3, t = (e >> 2) % 9, ci = e / 36;
+  dst[e] = co < Cout ? oihw[((size_t)co * Cin + ci) * 9 + t] : 0.f;
+}
 inline int conv_thin_grid_tiles(const ConvArgs& a, int tiles_x_widest) { return a.B * ((a.H + ConvThinGeom::TH - 1) / ConvThinGeom::TH) * tiles_x_widest; }
 
 template <int ACT>
 __global__ __launch_bounds__(256, 3) void conv3x3_thin_kernel(ConvArgs p) {
   using G = ConvThinGeom;
   __shared__ alignas(16) float s_in[2][G::KC * G::PLANE];
+  __shared__ alignas(16) float s_w[2][G::KC * 36];
   __shared__ float s_sc[512];
   __shared__ float s_sh[512];
   const int tid = threadIdx.x;
@@ -59,18 +70,17 @@ __global__ __launch_bounds__(256, 3) void conv3x3_thin_kernel(ConvArgs p) {
   // staging elements of this thread: NI positions (tile row r, tile column c; c fastest: a wave's loads of a row are consecutive) of each
   // of the stage's KC channels -- the channel is uniform per load, so the position's offsets are shared by the channels
   int it_goff[G::NI], it_loff[G::NI];
-  unsigned ok_mask = 0, live_mask = 0;
+  unsigned ok_mask = 0;
 #pragma unroll
   for (int i = 0; i < G::NI; ++i) {
     int e = tid + 256 * i;
-    const bool live = e < G::NPOS;
-    e = live ? e : G::NPOS - 1;
+    e = e < G::NPOS ? e : G::NPOS - 1;                            // (surplus lanes repeat the last position: same value to the same address)
     const int r = e / (G::TW + 2), c = e - r * (G::TW + 2);
     const int gy = y0 - 1 + r, gx = x0 - 1 + c;
     const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
     it_goff[i] = ok ? gy * W + gx : 0;
     it_loff[i] = r * G::LC + c;
-    ok_mask |= (unsigned)ok << i; live_mask |= (unsigned)live << i;
+    ok_mask |= (unsigned)ok << i;
   }
   float rin[G::KC][G::NI];
   auto load_stage = [&](int c0) {
@@ -82,6 +92,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_thin_kernel(ConvArgs p) {
       for (int i = 0; i < G::NI; ++i) rin[k][i] = base[(size_t)k * HW + it_goff[i]];
   };
   auto store_stage = [&](int c0, float* sbuf) {
+    int okm = (int)ok_mask;
+    DRT_PIN_INT(okm);                 // (re-derived per stage: hoisted out of the K loop the 5 lane masks and their uses cost more SGPRs than the kernel has)
 #pragma unroll
     for (int k = 0; k < G::KC; ++k) {
       const float sc = s_sc[c0 + k], sh = s_sh[c0 + k];
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_thin_kernel(ConvArgs p) {
       for (int i = 0; i < G::NI; ++i) {
         float t = rin[k][i] * sc + sh;
         if constexpr (ACT == 1) t = silu_f(t);
-        if ((live_mask >> i) & 1) sbuf[k * G::PLANE + it_loff[i]] = ((ok_mask >> i) & 1) ? t : 0.f;   // zero padding applies to the producer's OUTPUT
+        sbuf[k * G::PLANE + it_loff[i]] = ((okm >> i) & 1) ? t : 0.f;   // zero padding applies to the producer's OUTPUT
       }
     }
   };
@@ -101,39 +113,66 @@ __global__ __launch_bounds__(256, 3) void conv3x3_thin_kernel(ConvArgs p) {
     for (int px = 0; px < 4; ++px) acc[cp][px] = f32x2{0.f, 0.f};
 
   const int nst = Cin / G::KC;
+  // one step = one input channel x one kernel row: 3 weight quads (wave-uniform LDS reads: broadcasts) and the thread's 6 staged
+  // values of that row, both requested one step ahead of the 24 packed FMAs that use them
+  auto load_wq = [&](f32x4 (&w)[3], const float* wcur, int q) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) w[dx] = *reinterpret_cast<const f32x4*>(wcur + (q * 3 + dx) * 4);
+  };
+  auto load_in = [&](float (&in)[6], const float* cur, int q) {          // q = 3 k + dy within the stage
+    const float* src = cur + (q / 3) * G::PLANE + (row + q % 3) * G::LC + cx;
+    const f32x4 v4 = *reinterpret_cast<const f32x4*>(src);
+    const f32x2 v2 = *reinterpret_cast<const f32x2*>(src + 4);
+    in[0] = v4[0]; in[1] = v4[1]; in[2] = v4[2]; in[3] = v4[3]; in[4] = v2[0]; in[5] = v2[1];
+  };
+  auto fmas = [&](const f32x4 (&w)[3], const float (&in)[6]) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const f32x2 w01 = {w[dx][0], w[dx][1]}, w23 = {w[dx][2], w[dx][3]};
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        const f32x2 v = {in[px + dx], in[px + dx]};
+        acc[0][px] = drt_fma2(w01, v, acc[0][px]);
+        acc[1][px] = drt_fma2(w23, v, acc[1][px]);
+      }
+    }
+  };
+  constexpr int NQ = 3 * G::KC;
+  static_assert(NQ % 2 == 0 && NQ * 3 <= 64, "alternating operand sets; one wave stages a stage's weight quads");
+  // the stage's 36 weight quads travel with the tile: global -> register (threads 0..35) -> LDS
+  const f32x4* wq = reinterpret_cast<const f32x4*>(p.w);          // packed [ci][tap][4 co]
+  f32x4 rw = {0.f, 0.f, 0.f, 0.f};
+  f32x4 w[2][3];
+  float in[2][6];
   load_stage(0);
+  if (tid < NQ * 3) rw = wq[tid];
   __syncthreads();                    // s_sc / s_sh visible
   store_stage(0, s_in[0]);
+  if (tid < NQ * 3) *reinterpret_cast<f32x4*>(&s_w[0][tid * 4]) = rw;
   __syncthreads();
 #pragma unroll 1
   for (int st = 0; st < nst; ++st) {
     const float* cur = s_in[st & 1];
-    if (st + 1 < nst) load_stage((st + 1) * G::KC);               // in flight during the FMAs below
-#pragma unroll 1
-    for (int k = 0; k < G::KC; ++k) {                            // (not unrolled: one channel's 36 weights in SGPRs at a time)
-      const int ci = st * G::KC + k;
-      // wave-uniform weights of input channel ci: [co][tap] (OIHW source: scalar loads)
-      f32x2 wv[2][9];
-#pragma unroll
-      for (int cp = 0; cp < 2; ++cp)
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-          wv[cp][t] = f32x2{2 * cp < p.Cout ? p.w[((size_t)(2 * cp) * Cin + ci) * 9 + t] : 0.f, 2 * cp + 1 < p.Cout ? p.w[((size_t)(2 * cp + 1) * Cin + ci) * 9 + t] : 0.f};
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const float* q = cur + k * G::PLANE + (row + dy) * G::LC + cx;
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(q);
-        const float2 v2 = *reinterpret_cast<const float2*>(q + 4);
-        const float in[6] = {v4[0], v4[1], v4[2], v4[3], v2.x, v2.y};
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-          for (int cp = 0; cp < 2; ++cp)
-#pragma unroll
-            for (int px = 0; px < 4; ++px) acc[cp][px] = drt_fma2(wv[cp][dy * 3 + dx], f32x2{in[px + dx], in[px + dx]}, acc[cp][px]);
-      }
+    const float* wcur = s_w[st & 1];
+    const bool more = st + 1 < nst;
+    load_in(in[0], cur, 0); load_wq(w[0], wcur, 0);
+    if (more) {                                                    // in flight during the FMAs below
+      load_stage((st + 1) * G::KC);
+      if (tid < NQ * 3) rw = wq[(st + 1) * (NQ * 3) + tid];
     }
-    if (st + 1 < nst) store_stage((st + 1) * G::KC, s_in[(st + 1) & 1]);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q + 1 < NQ) { load_in(in[(q + 1) & 1], cur, q + 1); load_wq(w[(q + 1) & 1], wcur, q + 1); }
+      DRT_SCHED_FENCE();              // requests first, then the FMAs that cover their latency ...
+      fmas(w[q & 1], in[q & 1]);
+      // ... and each step stays where it is written (left alone, the scheduler issues the LDS reads of all 12 steps up front: 157 spilled VGPRs)
+      DRT_PIN8(acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+      DRT_SCHED_FENCE();
+    }
+    if (more) {
+      store_stage((st + 1) * G::KC, s_in[(st + 1) & 1]);
+      if (tid < NQ * 3) *reinterpret_cast<f32x4*>(&s_w[(st + 1) & 1][tid * 4]) = rw;
+    }
     __syncthreads();
   }
 

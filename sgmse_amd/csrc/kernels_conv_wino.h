@@ -152,7 +152,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   // (One workgroup owns a CU and every workgroup of a launch takes the same time, so all 256 CUs run their K loops and then their
   //  epilogues in lock step.  De-phasing the first residency round by up to a tile time did not shorten the epilogue -- it is bound by
   //  the CU's own vector-memory issue rate, ~25 cycles per wave instruction, not by the simultaneous burst -- and cost its start-up
-  //  delay: profiles/r04_wino_microbench_history.txt visit r04b, r04_wino_trace.txt; removed.)
+  //  delay: profiles/r04_wino_microbench_history.txt visit r04b, r04_wino_trace.txt; removed.  Static issue priority for one half of the
+  //  workgroup (s_setprio 1 for the B-waves, or for the A-waves, before the K loop) measured within +-1 % on three shapes: same file, visit
+  //  r04p.  16-byte output stores (neighbouring lanes trade column pairs by DPP so that each stores 4 columns of one channel: half the
+  //  store instructions) measured 0.930 / 1.502 / 0.351 ms against 0.922 / 1.491 / 0.352: no gain, visit r04w -- and the B-waves' queued
+  //  x4 stores then picked up first dwords that later VALU instructions had already overwritten (non-repeatable; 8-byte stores do not).)
   const int Cin = p.C1 + p.C2;
   const int tiles_xg = (p.W + 31) >> 5;
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
