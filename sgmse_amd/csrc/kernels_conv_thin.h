@@ -11,7 +11,8 @@
 // which scalar loads force: 8.4 k cycles per 4-channel stage with one wave per SIMD, profiles/r04_thin_kernel.txt.)
 //
 //   workgroup = 256 threads = 16 rows x 64 columns of one utterance (thread: row t / 16, columns 4 (t % 16) .. + 3), 3 per CU;
-//   the FMAs are packed over output-channel pairs (v_pk_fma_f32: weight pair from SGPRs, the input value broadcast to both halves);
+//   the FMAs are packed over output-channel pairs (v_pk_fma_f32: weight pair x the input value broadcast to both halves; four
+//   v_fmac_f32 in their place measured 3-4 % slower at batch 32 and 13 % at batch 1, profiles/r04_thin_kernel.txt);
 //   K-stages of 4 input channels: the tile with halo (18 x 66, row stride 68 floats so that a thread's 16-byte read is aligned) after the
 //   fused producer (GroupNorm affine + SiLU, zero padding applied behind it), double-buffered in LDS (2 x 19.6 KB: three workgroups per
 //   CU); the raw values of stage s + 1 are loaded (coalesced dwords, 20 per thread) before the FMAs of stage s and pass the producer behind them;
