@@ -292,6 +292,7 @@ class Engine {
     if (graph_valid_ || graph_stale_) drt::graph_destroy(&graph_);
     if (hstage_) drt::free_host(hstage_);
     if (hstage_ev_init_) drt::event_destroy(&hstage_ev_);
+    for (ProfRec& r : prof_recs_) { drt::event_destroy(&r.a); drt::event_destroy(&r.b); }
   }
 
   drt::stream_t stream() const { return stream_; }
@@ -769,8 +770,22 @@ class Engine {
                        int* launches_out) {
     prof_ = true;
     for (int i = 0; i < TC_COUNT; ++i) { prof_ms_[i] = 0.f; prof_flops_[i] = 0.0; prof_n_[i] = 0; }
+    prof_used_ = 0;
     forward_xy(xy, t_dev, out, B, F, T);
     prof_ = false;
+    // the event pairs are read after the whole forward has been queued: launches then follow each other as in the replayed graph
+    // (with a wait after every launch the device idled between them and each interval carried ~40 us of dispatch: the class times
+    // were 4-5 % above the kernel durations rocprofv3 reports for the captured step)
+    SG_CHECK(drt::stream_sync(stream_));
+    for (size_t i = 0; i < prof_used_; ++i) {
+      ProfRec& r = prof_recs_[i];
+      if (r.cls < 0) continue;                      // (a tock() without its tick())
+      const float ms = drt::event_elapsed_ms(r.a, r.b);
+      prof_ms_[r.cls] += ms;
+      prof_flops_[r.cls] += r.work;
+      prof_n_[r.cls] += r.launches;
+      if (prof_dump_ && r.note[0]) fprintf(stderr, "[sgmse-prof] %s %.4f ms %.1f Gwork/s\n", r.note, ms, r.work / ms * 1e-6);
+    }
     for (int i = 0; i < TC_COUNT; ++i) { ms_out[i] = prof_ms_[i]; work_out[i] = prof_flops_[i]; launches_out[i] = prof_n_[i]; }
   }
 
@@ -1108,18 +1123,26 @@ class Engine {
       fflush(stderr);
       if (!prof_) prof_note_[0] = 0;
     }
-    if (!prof_) return;
-    drt::event_record(&ev_b_, stream_);
-    drt::event_sync(&ev_b_);
-    const float ms = drt::event_elapsed_ms(ev_a_, ev_b_);
-    prof_ms_[cls] += ms;
-    prof_flops_[cls] += work;
-    prof_n_[cls] += launches;
-    if (prof_dump_ && prof_note_[0]) fprintf(stderr, "[sgmse-prof] %s %.4f ms %.1f Gwork/s\n", prof_note_, ms, work / ms * 1e-6);
+    if (!prof_ || prof_used_ == 0) return;
+    ProfRec& r = prof_recs_[prof_used_ - 1];
+    drt::event_record(&r.b, stream_);
+    r.cls = cls; r.work = work; r.launches = launches;
+    snprintf(r.note, sizeof r.note, "%s", prof_note_);
     prof_note_[0] = 0;
   }
   bool noting() const { return (prof_ && prof_dump_) || debug_sync_; }
-  void tock() { if (prof_) { if (!ev_init_) { drt::event_create(&ev_a_); drt::event_create(&ev_b_); ev_init_ = true; } drt::event_record(&ev_a_, stream_); } }
+  // one event pair per launch of a profiled forward (created on first use, reused by later profiles, destroyed with the engine)
+  struct ProfRec { drt::event_t a{}, b{}; int cls = -1; double work = 0.0; int launches = 0; char note[160] = {0}; };
+  void tock() {
+    if (!prof_) return;
+    if (prof_used_ == prof_recs_.size()) {
+      prof_recs_.emplace_back();
+      drt::event_create(&prof_recs_.back().a); drt::event_create(&prof_recs_.back().b);
+    }
+    ProfRec& r = prof_recs_[prof_used_++];
+    r.cls = -1; r.note[0] = 0;
+    drt::event_record(&r.a, stream_);
+  }
 
   Tensor new_tensor(int C, int H, int W) { Tensor t; t.C = C; t.H = H; t.W = W; t.p = arena_.alloc((size_t)C * pix_total(H, W)); return t; }
 
@@ -1793,7 +1816,7 @@ class Engine {
   float *temb_act_ = nullptr, *bias_table_ = nullptr, *step_table_ = nullptr, *tsteps_ = nullptr, *coef_table_ = nullptr; int temb_rows_ = 0;
   drt::graph_t graph_{}; bool graph_valid_ = false; GraphKey graph_key_{};
   int nfe_ = 0;
-  bool prof_ = false, ev_init_ = false; drt::event_t ev_a_{}, ev_b_{}; float prof_ms_[TC_COUNT]; double prof_flops_[TC_COUNT]; int prof_n_[TC_COUNT];
+  bool prof_ = false; std::vector<ProfRec> prof_recs_; size_t prof_used_ = 0; float prof_ms_[TC_COUNT]; double prof_flops_[TC_COUNT]; int prof_n_[TC_COUNT];
 };
 
 }  // namespace sgmse

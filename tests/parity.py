@@ -218,6 +218,30 @@ def check_forward_golden(dev, name, batch=None):
     assert err < NET_TOL, (name, err)
 
 
+def check_profile_forward(dev, name, batch=1):
+    """The per-class profile of one evaluation (what bench.py's roofline object is computed from): event pairs are recorded per
+    launch and read after the whole forward has been queued; the forward it times is the ordinary one, bit for bit, every
+    launch is attributed to a class, and a second profile reuses the events."""
+    cfg = NET_CASES[name]
+    z = load(name)
+    net, _ = make_backbone(cfg, dev)
+    x, t = torch.from_numpy(z["x"])[:batch].to(dev), torch.from_numpy(z["t"])[:batch].to(dev)
+    ref = net(x, t)
+    ctx = net.engine(x.device)
+    xy = x.contiguous()
+    prof, out = ctx.profile_forward(xy, t)
+    prof2, out2 = ctx.profile_forward(xy, t)
+    assert torch.equal(out.reshape(ref.shape), ref) and torch.equal(out2, out)
+    assert set(prof) == set(prof2)
+    n = sum(v["launches"] for v in prof.values())
+    assert n > 50 and n == sum(v["launches"] for v in prof2.values()), n
+    for k, v in prof.items():
+        assert v["ms"] >= 0.0 and v["work"] >= 0.0
+        assert (v["launches"] > 0) == (v["work"] > 0.0), (k, v)
+        assert v["work"] == prof2[k]["work"]
+    assert prof["conv3x3_other"]["launches"] + prof["conv3x3_wide"]["launches"] > 0
+
+
 def check_tile_independence(dev, name, batch=None):
     """The conv tile shape follows the workgroup count (batch size, U-Net level), so it must never change a bit of the
     result: widest tiles everywhere vs narrowest tiles everywhere (SGMSE_TILE_MIN_BLOCKS is read at engine creation)."""

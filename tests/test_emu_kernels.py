@@ -156,6 +156,10 @@ def test_forward_matches_reference_ncsnpp(emu):
     P.check_forward_golden(emu, "fwd_nf32", batch=1)
 
 
+def test_profile_of_one_evaluation_times_the_ordinary_forward(emu):
+    P.check_profile_forward(emu, "fwd_nf32")
+
+
 def test_conv_tile_shape_never_changes_a_bit(emu):
     P.check_tile_independence(emu, "fwd_nf32", batch=1)
 

@@ -483,6 +483,10 @@ def test_maximum_batch_more_than_2_to_the_31_activation_elements(hip):
     net(x3, t3)                                  # back to a small shape: the arena is re-planned (and stays allocated)
 
 
+def test_profile_of_one_evaluation_times_the_ordinary_forward(hip):
+    P.check_profile_forward(hip, "fwd_nf32")
+
+
 def test_conv_tile_shape_never_changes_a_bit(hip):
     P.check_tile_independence(hip, "fwd_nf32")
 
