@@ -134,17 +134,10 @@ __device__ __forceinline__ int drt_uniform(int v) { return __builtin_amdgcn_read
 // executes its LDS operations in order, so this only pins the compiler's ordering (the emulator synchronises its fibers)
 __device__ __forceinline__ void drt_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #define DRT_PIN_HERE(x) asm volatile("" : "+v"(x))
-// Wave-uniform 16-byte loads through the scalar cache whose ISSUE POINT the caller fixes (left to the compiler, the load vectoriser merges
-// the loads of many steps into wide ones at the top of the block: their SGPRs then live across the whole block and spill).  The value
-// is valid only behind DRT_SLOAD_WAIT3 on it (s_waitcnt lgkmcnt(0): scalar loads return out of order, there is no partial wait).
-#define DRT_SLOAD4(dst, ptr, byte_off) asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(dst) : "s"(ptr), "n"(byte_off))
 // the machine scheduler moves nothing across this point
 #define DRT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// pins 8 register pairs at this point of the volatile-asm order (pure arithmetic is otherwise free to sink below later asm statements)
+// pins 8 register pairs at this point of the program (pure arithmetic is otherwise free to sink below a later block)
 #define DRT_PIN8(a, b, c, d, e, f, g, h) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
-// (the builtin, not asm text: the compiler's own wait-count bookkeeping sees it and stops counting the earlier LDS reads as outstanding;
-// 0xC07F = lgkmcnt(0) with vmcnt / expcnt left at their maxima)
-#define DRT_SLOAD_WAIT3(a, b, c) do { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" : "+s"(a), "+s"(b), "+s"(c)); } while (0)
 #define DRT_PIN_INT(x) asm volatile("" : "+v"(x))
 #define DRT_CODE_MARKER(n) asm volatile("; code marker %0" ::"n"(n))
 #define DRT_LAUNCH(kern, grid, block, stream, ...) \

@@ -146,8 +146,6 @@ static inline double drt_shfl_xor_f64(double v, int mask) {
 
 static inline void drt_wave_sync() { (void)emu::shfl_idx(0.f, 0); }
 #define DRT_PIN_HERE(x) ((void)0)
-#define DRT_SLOAD4(dst, ptr, byte_off) (dst) = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ptr) + (byte_off))
-#define DRT_SLOAD_WAIT3(a, b, c) ((void)0)
 #define DRT_SCHED_FENCE() ((void)0)
 #define DRT_PIN8(a, b, c, d, e, f, g, h) ((void)0)
 #define DRT_PIN_INT(x) ((void)0)
