@@ -160,6 +160,29 @@ def pc_sample(sde: OUVE, score: Callable, y: torch.Tensor, noise: Callable, *, e
         return (xm if denoise else xt), sde.N * (n_corr + 1)
 
 
+def ode_sample_adaptive(sde: OUVE, score: Callable, y: torch.Tensor, noise: Callable, *, eps=0.03, rtol=1e-5, atol=1e-5,
+                        method="RK45") -> Tuple[torch.Tensor, int]:
+    """The reference's black-box probability-flow sampler with ``denoise=False`` (sampling/__init__.py:96-143; with the default
+    ``denoise=True`` the reference raises TypeError at :101).  The solver is the third-party scipy.integrate.solve_ivp
+    (reference pin scipy==1.10.1, requirements_version.txt:14; Dormand-Prince RK45 with scipy's step control -- not restated here,
+    called as the reference calls it at :128-131); restated are the drift handed to it -- rsde.sde(...)[0] with
+    probability_flow=True: theta (y - x) - g(t)^2 score / 2 (sdes.py:113-128, :188-196) -- and the flattening of the complex
+    state (utils/other.py: to_flattened_numpy / from_flattened_numpy)."""
+    from scipy import integrate
+    with torch.no_grad():
+        x = sde.prior(y, noise)
+
+        def ode_func(t, xflat):
+            xt = torch.from_numpy(xflat.reshape(tuple(y.shape))).type(torch.complex64)
+            vec_t = torch.ones(y.shape[0]) * t
+            g = sde.diffusion(vec_t)
+            drift = sde.drift(xt, y) - g[:, None, None, None] ** 2 * score(xt, y, vec_t) * 0.5
+            return drift.detach().cpu().numpy().reshape((-1,))
+
+        sol = integrate.solve_ivp(ode_func, (sde.T, eps), x.detach().cpu().numpy().reshape((-1,)), rtol=rtol, atol=atol, method=method)
+        return torch.tensor(sol.y[:, -1]).reshape(y.shape).type(torch.complex64), int(sol.nfev)
+
+
 class NoiseReplay:
     """Deterministic complex standard-normal stream (SURVEY 8-d 'Noise').
     Draw k has shape ``like.shape``; values come from a dedicated CPU generator so

@@ -1,6 +1,6 @@
 """Stand-in for the `soundfile` package, for machines that do not have it (this image): just what the reference's scripts call --
 ``write(path, data, samplerate)`` (enhancement.py:103) and ``read(path)`` (calc_metrics.py) -- on top of ``scipy.io.wavfile``.
-wav only, float32 samples.  Put `sgmse_amd/compat/shims` on PYTHONPATH only where the real package is missing."""
+Writes wav (float32 samples); reads wav and, through sgmse_amd/util/flac.py, flac.  Put `sgmse_amd/compat/shims` on PYTHONPATH only where the real package is missing."""
 import os
 
 import numpy as np
@@ -16,6 +16,11 @@ def write(file, data, samplerate, subtype=None, **_ignored):
 
 
 def read(file, dtype="float64", always_2d=False, **_ignored):
+    from sgmse_amd.util.flac import is_flac, read_flac
+    if is_flac(file):
+        xi, sr, bits = read_flac(file)
+        x = (xi.astype(np.float64) / float(2 ** (bits - 1))).astype(dtype)
+        return (x if always_2d or x.shape[1] > 1 else x[:, 0]), int(sr)
     sr, x = wavfile.read(file)
     if x.dtype.kind == "i":
         x = x.astype(np.float64) / float(2 ** (8 * x.dtype.itemsize - 1))

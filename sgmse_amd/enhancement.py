@@ -20,7 +20,8 @@ Differences from the reference script, none of them in the arithmetic of one utt
   reads the checkpoint and the weights reach the other ranks in one RCCL broadcast; there is no collective on the data path;
 * every file is read / resampled once on background threads ahead of the GPU, and the inverse transform + file writes of a
   batch overlap the sampling of the next one;
-* audio I/O uses ``soundfile`` when it is installed and ``scipy.io.wavfile`` (wav only) otherwise; resampling to the
+* audio I/O uses ``soundfile`` when it is installed; otherwise ``scipy.io.wavfile`` for wav and the package's own decoder
+  (util/flac.py) for flac input; resampling to the
   model's rate uses ``scipy.signal.resample_poly`` (the reference: ``librosa.resample``).
 """
 from __future__ import annotations
@@ -48,6 +49,10 @@ def read_audio(path: str) -> Tuple[np.ndarray, int]:
         x, sr = soundfile.read(path, dtype="float32", always_2d=True)
         return np.ascontiguousarray(x[:, 0]), int(sr)
     except ImportError:
+        from .util.flac import is_flac, read_flac
+        if is_flac(path):                               # (scipy reads wav only; the reference's glob also yields *.flac)
+            xi, sr, bits = read_flac(path)
+            return np.ascontiguousarray(xi[:, 0].astype(np.float32) / float(2 ** (bits - 1))), int(sr)
         from scipy.io import wavfile
         sr, x = wavfile.read(path)
         if x.ndim > 1:
@@ -70,7 +75,7 @@ def write_audio(path: str, x: np.ndarray, sr: int) -> None:
 
 
 def list_audio(test_dir: str) -> List[str]:
-    """Same globbing order as the reference (``enhancement.py:39-43``); scipy can only read the wav files."""
+    """Same globbing order as the reference (``enhancement.py:39-43``)."""
     files: List[str] = []
     for pat in ("*.wav", join("**", "*.wav"), "*.flac", join("**", "*.flac")):
         files += sorted(glob.glob(join(test_dir, pat)))
@@ -125,7 +130,11 @@ def probe_samples(path: str, target_sr: int) -> int:
         info = soundfile.info(path)
         n, sr = int(info.frames), int(info.samplerate)
     except ImportError:
+        from .util.flac import flac_info, is_flac
         from scipy.io import wavfile
+        if is_flac(path):
+            n, sr, _, _ = flac_info(path)
+            return n if sr == target_sr else -(-n * (target_sr // gcd(sr, target_sr)) // (sr // gcd(sr, target_sr)))
         try:
             sr, x = wavfile.read(path, mmap=True)          # maps the data chunk: the header gives the shape
             n = int(x.shape[0])

@@ -434,6 +434,38 @@ def replay_noise(shape, ndraws, seed=7):
     return torch.stack([rep(like) for _ in range(ndraws)])
 
 
+def check_ode_rk45(dev, full=True):
+    """The reference's adaptive probability-flow sampler (get_ode_sampler with denoise=False: scipy RK45 over the flattened state,
+    sampling/__init__.py:96-143) against the reference's own run (tests/golden/ode_rk45.npz, oracle/make_golden_ode.py).
+    The trajectory of the random-weight network is sensitive (the oracle's own end state is 3.7e-4 from the reference's), so the parity
+    gate sits where the product computes: the drift handed to the solver, at the reference's own evaluation points (1e-5); the end
+    state is bounded at 2e-2 and the solver's evaluation count must stay within two steps of the reference's."""
+    from sgmse_amd import sampling
+    z = load("ode_rk45")
+    cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
+    m, _ = make_model(cfg, dev)
+    y = torch.from_numpy(z["y"]).to(dev)
+    sde = m.sde.copy()
+    rsde = sde.reverse(m, probability_flow=True)
+    worst = 0.0
+    with torch.no_grad():
+        for t, xk, fk in zip(z["probe_t"], z["probe_x"], z["probe_f"]):
+            xt = torch.from_numpy(xk.reshape(tuple(y.shape))).to(dev)
+            f = rsde.sde(xt, y, torch.ones(y.shape[0], device=dev) * float(t))[0]
+            worst = max(worst, rel_l2(f.cpu().reshape(-1), torch.from_numpy(fk)))
+    print(f"ode_rk45 on {dev}: drift at {len(z['probe_t'])} of the reference's evaluation points, worst rel_l2 = {worst:.3e}")
+    assert worst < 1e-5, worst
+    if not full:
+        return
+    noise = replay_noise(tuple(y.shape), 1).to(dev)
+    sampler = m.get_ode_sampler(y, denoise=False, rtol=float(z["rtol"]), atol=float(z["atol"]), method="RK45", noise=noise)
+    out, nfe = sampler()
+    err = rel_l2(out.cpu(), torch.from_numpy(z["out"]))
+    print(f"ode_rk45 on {dev}: solver evaluations {nfe} (reference {int(z['nfe'])}), end state rel_l2 vs the reference's = {err:.3e} "
+          f"(the oracle's own: {float(z['oracle_vs_reference']):.3e})")
+    assert abs(nfe - int(z["nfe"])) <= 12 and err < 2e-2, (nfe, err)
+
+
 def check_sampler_golden(dev, tag, batch=None, use_graph=True):
     """get_pc_sampler(...)() with replayed noise against the reference's own sampler output (fixture).  Utterances in
     a batch are independent on this path, so a batch prefix of the fixture is a valid smaller case."""

@@ -176,6 +176,11 @@ def test_forward_matches_reference_ncsnpp_v2(emu):
     P.check_forward_golden(emu, "fwd_v2_nf32")
 
 
+def test_adaptive_ode_sampler_drift_matches_the_reference_at_its_evaluation_points(emu):
+    """(the whole 92-evaluation trajectory on the emulator: SGMSE_SLOW=1; on the GPU it always runs)"""
+    P.check_ode_rk45(emu, full=bool(os.environ.get("SGMSE_SLOW")))
+
+
 def test_sampler_new_code_score_wrapper(emu):
     P.check_sampler_v2(emu, "denoiser", "1/sigma", "edm", "1", "0", N=1)
 

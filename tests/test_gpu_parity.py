@@ -483,6 +483,11 @@ def test_maximum_batch_more_than_2_to_the_31_activation_elements(hip):
     net(x3, t3)                                  # back to a small shape: the arena is re-planned (and stays allocated)
 
 
+def test_adaptive_ode_sampler_matches_the_reference_run(hip):
+    """get_ode_sampler(denoise=False): the reference's scipy RK45 path, every function evaluation one network evaluation on the GPU."""
+    P.check_ode_rk45(hip)
+
+
 def test_profile_of_one_evaluation_times_the_ordinary_forward(hip):
     P.check_profile_forward(hip, "fwd_nf32")
 

@@ -134,3 +134,26 @@ def test_sb_sampler_matches_reference(stype):
     model = lambda a, b, c: NO.score_fn_v2(P, cfg, sv, a, b, c, loss_type="data_prediction")
     out, n = SO.sb_sample(SO.SBVE(2.6, 0.4, 4), model, torch.from_numpy(z["y"]), SO.NoiseReplay(7), eps=1e-4, sampler_type=stype)
     assert n == 4 and rel_l2(out, z["out"]) < 1e-4
+
+
+def test_adaptive_ode_oracle_reproduces_the_reference_drift_and_run():
+    """oracle/sde_oracle.py::ode_sample_adaptive against the reference's get_ode_sampler(denoise=False) run (tests/golden/ode_rk45.npz,
+    oracle/make_golden_ode.py): the drift at the reference's own evaluation points always; the whole trajectory under SGMSE_SLOW=1."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ode_rk45.npz"))
+    cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
+    P = synth.synth_params(cfg, seed=0)
+    y = torch.from_numpy(z["y"])
+    so = SO.OUVE(1.5, 0.05, 0.5, 30)
+    assert bool(z["default_call_raises_typeerror"])          # what the fixed-step sampler (SURVEY 8-a9) stands in for
+    for t, xk, fk in zip(z["probe_t"][:3], z["probe_x"][:3], z["probe_f"][:3]):
+        xt = torch.from_numpy(xk.reshape(tuple(y.shape)))
+        vt = torch.ones(y.shape[0]) * float(t)
+        f = so.drift(xt, y) - so.diffusion(vt)[:, None, None, None] ** 2 * NO.score_fn(P, cfg, xt, y, vt) * 0.5
+        err = float((f.reshape(-1) - torch.from_numpy(fk)).norm() / torch.from_numpy(fk).norm())
+        assert err < 1e-5, (float(t), err)
+    if os.environ.get("SGMSE_SLOW"):
+        out, nfe = SO.ode_sample_adaptive(so, lambda a, b, c: NO.score_fn(P, cfg, a, b, c), y, SO.NoiseReplay(7), eps=float(z["eps"]),
+                                          rtol=float(z["rtol"]), atol=float(z["atol"]))
+        err = float((out - torch.from_numpy(z["out"])).norm() / torch.from_numpy(z["out"]).norm())
+        assert nfe == int(z["nfe"]) and err < 2e-2, (nfe, err)
