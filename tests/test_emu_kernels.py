@@ -294,7 +294,8 @@ def test_ragged_launches_over_the_widest_utterances_grid_give_the_same_bits(emu,
     over the tile columns that exist, XCD-aware tile order) is what every other ragged test runs."""
     monkeypatch.setenv("SGMSE_RAGGED_PREFIX", "0")
     monkeypatch.setenv("SGMSE_CONV_XCD_MAP", "0")
-    P.check_ragged_batch(emu, "fwd_nf32", frames=(128, 64, 192), quick=True)
+    # (forward only on the emulator -- the samplers add two minutes here; the GPU test of the same name runs them too)
+    P.check_ragged_batch(emu, "fwd_nf32", frames=(128, 64, 192), sampler=bool(os.environ.get("SGMSE_SLOW")), quick=True)
 
 
 @pytest.mark.skipif(not os.environ.get("SGMSE_SLOW"), reason="full-width network on the emulator: minutes (SGMSE_SLOW=1)")
