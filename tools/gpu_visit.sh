@@ -15,6 +15,8 @@
 #   ragged     tools/ragged_bench.py
 #   dirjob     tools/dir_job_bench.py
 #   lengths    bench.py --seconds sweep (utterance lengths off the 512-frame grid)
+#   libab      same-box A/B of TWO builds of the library: LIB_A, LIB_B (paths; default the product library and `make persist`'s), in
+#              the order A B B A: the kernel micro-benchmark (VARIANTS / SHAPES) and bench.py at batch 32 and batch 1
 # Everything lands in gpurun_out/ with the TAG prefix; copy what is to be judged into profiles/.
 set +e
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
@@ -116,6 +118,24 @@ if has lengths; then
   for s in ${LENGTHS:-3.0 3.5 4.0 4.5 5.0}; do
     timeout 300 python bench.py --seconds $s --steps 2 --warmup 1 --no-others --no-cpu-baseline > $O/len_$s.json 2>/dev/null
     val $O/len_$s.json "seconds=$s" | tee -a $O/${TAG}_length_sweep.txt
+  done
+fi
+if has libab; then
+  LIB_A=${LIB_A:-sgmse_amd/libsgmse_hip.so}; LIB_B=${LIB_B:-sgmse_amd/libsgmse_hip_persist.so}
+  : > $O/${TAG}_libab.txt
+  runbench() { python -c "
+import sys, runpy
+from sgmse_amd import _lib
+_lib.load_library('$PWD/$1')
+sys.argv = ['bench.py'] + '$2'.split()
+runpy.run_path('bench.py', run_name='__main__')" 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('   ', round(d['value'], 4), d['unit'], round(d['ms_per_step'], 1), 'ms/step')"; }
+  for L in $LIB_A $LIB_B $LIB_B $LIB_A; do
+    echo "== lib: $L" | tee -a $O/${TAG}_libab.txt
+    SGMSE_LIB_PATH=$PWD/$L VARIANTS=${VARIANTS:-1152} SHAPES=${SHAPES:-0,1,2} FUSED=1 ROUNDS=3 timeout 200 python tools/conv_microbench.py 2>&1 | grep "ms " | tee -a $O/${TAG}_libab.txt
+    runbench $L "--steps 2 --warmup 1 --no-others --no-cpu-baseline --no-profile" | tee -a $O/${TAG}_libab.txt
+    runbench $L "--batch 1 --steps 3 --warmup 1 --no-others --no-cpu-baseline --no-profile" | tee -a $O/${TAG}_libab.txt
   done
 fi
 echo "== done"
