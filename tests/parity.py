@@ -122,6 +122,24 @@ def check_conv_wino(dev, B, Ci, Co, H, W, dual=0, xform=True, res=True, xmul=1.0
     assert e_w < max(slack * e_f32, 3e-7), (e_w, e_f32)
 
 
+def check_conv_thin_batch_independence(dev):
+    """The VALU kernel of the pyramid convolutions gives an utterance the same bits alone and inside a batch (its accumulation order is a
+    function of the layer only), with and without the residual / producer, at widths that leave partial 16 x 64 tiles."""
+    from sgmse_amd import ops
+    g = gen(91)
+    B, Ci, H, W = 3, 64, 20, 72
+    x = R(g, B, Ci, H, W); w = R(g, 4, Ci, 3, 3) / math.sqrt(Ci * 9); b = R(g, 4); r = R(g, B, 4, H, W)
+    sc, sh = R(g, B, Ci), R(g, B, Ci)
+    mv = lambda t: None if t is None else t.to(dev)
+    for res, xf in ((True, True), (False, False)):
+        kw = lambda sl: dict(residual=mv(r[sl]) if res else None, out_scale=0.5, in_scale=mv(sc[sl]) if xf else None,
+                             in_shift=mv(sh[sl]) if xf else None, in_act=xf, force_split="thin")
+        full = ops.conv2d(mv(x), mv(w), mv(b), **kw(slice(None))).cpu()
+        for i in range(B):
+            one = ops.conv2d(mv(x[i:i + 1]), mv(w), mv(b), **kw(slice(i, i + 1))).cpu()
+            assert torch.equal(one[0], full[i]), (res, xf, i)
+
+
 def check_groupnorm(dev, B, C, H, W, act=True, dual=0):
     from sgmse_amd import ops
     g = gen(C + H)

@@ -90,6 +90,10 @@ def test_conv3x3_thin_output_valu_kernel(hip):
     P.check_conv_b3(hip, 1, 96, 4, 5, 32, dual=32, xform=True, split="thin", slack=1.5)
 
 
+def test_conv3x3_thin_output_valu_kernel_is_batch_independent(hip):
+    P.check_conv_thin_batch_independence(hip)
+
+
 def test_conv3x3_thin_output_split_kernel(hip):
     """C -> 4 pyramid convolutions on the split kernel's thin variant (one padded 32-channel fragment, waves split pixels)."""
     P.check_conv_b3(hip, 1, 64, 4, 9, 33, xform=True, split="fp16x2", slack=3.0)
