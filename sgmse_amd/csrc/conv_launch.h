@@ -166,38 +166,27 @@ inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t
 inline bool conv_wino_eligible(int C1, int C2, int Cout, int W) {
   return Cout % 128 == 0 && (C1 + C2) % 16 == 0 && (C2 == 0 || C1 % 16 == 0) && (C1 + C2) <= 512 && W % 2 == 0;
 }
-#ifdef SGMSE_WINO_PERSISTENT
-// comparison build: SGMSE_WINO_PERSIST = total workgroups of a launch (256 = one per CU; 0 = one per tile), read once
-inline int wino_persist_wgs() { static const int v = [] { const char* e = getenv("SGMSE_WINO_PERSIST"); return e ? atoi(e) : 256; }(); return v; }
-#define SGMSE_WINO_LAUNCH(KERN, TILES) do { const int nt_ = (TILES), cb_ = a.Cout / 128; int gx_ = nt_; \
-    const int cap_ = (wino_persist_wgs() / cb_) & ~7;      /* a multiple of 8: the XCD-aware tile order */ \
-    if (cap_ >= 8 && nt_ > cap_) gx_ = cap_; \
-    DRT_LAUNCH(KERN, dim3(gx_, cb_, 1), dim3(512), st, a, nt_); } while (0)
-#else
-#define SGMSE_WINO_LAUNCH(KERN, TILES) DRT_LAUNCH(KERN, dim3((TILES), a.Cout / 128, 1), dim3(512), st, a)
-#endif
 inline void launch_conv_wino(const ConvArgs& a, drt::stream_t st, bool rows4, bool trace = false, int abl = 0) {
   const bool act = a.in_scale && a.in_act;
 #ifdef SGMSE_ABLATION_FULL
-#define SGMSE_WABL_CASE(V) if (abl == V) { SGMSE_WINO_LAUNCH((conv3x3_wino_kernel<8, 1, 0, 0, V>), conv_grid_tiles(a, 8)); return; }
+#define SGMSE_WABL_CASE(V) if (abl == V) { DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0, 0, V>), dim3(conv_grid_tiles(a, 8), a.Cout / 128, 1), dim3(512), st, a); return; }
   SGMSE_WABL_CASE(1) SGMSE_WABL_CASE(2) SGMSE_WABL_CASE(4) SGMSE_WABL_CASE(8) SGMSE_WABL_CASE(16) SGMSE_WABL_CASE(24) SGMSE_WABL_CASE(3) SGMSE_WABL_CASE(32) SGMSE_WABL_CASE(20)
 #undef SGMSE_WABL_CASE
-  if (trace) { SGMSE_WINO_LAUNCH((conv3x3_wino_kernel<8, 1, 0, 1>), conv_grid_tiles(a, 8)); return; }
+  if (trace) { DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0, 1>), dim3(conv_grid_tiles(a, 8), a.Cout / 128, 1), dim3(512), st, a); return; }
 #endif
   (void)abl; (void)trace;
   if (rows4) {
-    const int nt = conv_grid_tiles(a, 4);
-    if (a.sc_w) SGMSE_WINO_LAUNCH((conv3x3_wino_kernel<4, 1, 1>), nt);
-    else if (act) SGMSE_WINO_LAUNCH((conv3x3_wino_kernel<4, 1, 0>), nt);
-    else SGMSE_WINO_LAUNCH((conv3x3_wino_kernel<4, 0, 0>), nt);
+    const dim3 grid(conv_grid_tiles(a, 4), a.Cout / 128, 1);
+    if (a.sc_w) DRT_LAUNCH((conv3x3_wino_kernel<4, 1, 1>), grid, dim3(512), st, a);
+    else if (act) DRT_LAUNCH((conv3x3_wino_kernel<4, 1, 0>), grid, dim3(512), st, a);
+    else DRT_LAUNCH((conv3x3_wino_kernel<4, 0, 0>), grid, dim3(512), st, a);
   } else {
-    const int nt = conv_grid_tiles(a, 8);
-    if (a.sc_w) SGMSE_WINO_LAUNCH((conv3x3_wino_kernel<8, 1, 1>), nt);
-    else if (act) SGMSE_WINO_LAUNCH((conv3x3_wino_kernel<8, 1, 0>), nt);
-    else SGMSE_WINO_LAUNCH((conv3x3_wino_kernel<8, 0, 0>), nt);
+    const dim3 grid(conv_grid_tiles(a, 8), a.Cout / 128, 1);
+    if (a.sc_w) DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 1>), grid, dim3(512), st, a);
+    else if (act) DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0>), grid, dim3(512), st, a);
+    else DRT_LAUNCH((conv3x3_wino_kernel<8, 0, 0>), grid, dim3(512), st, a);
   }
 }
-#undef SGMSE_WINO_LAUNCH
 
 // exact-fp32 VALU kernel of the C -> 4 pyramid convolutions (kernels_conv_thin.h); a.w = weights packed by pack_weights_thin_kernel
 inline void launch_conv_thin(const ConvArgs& a, drt::stream_t st) {

@@ -127,16 +127,8 @@ __global__ __launch_bounds__(256) void pack_weights_wino_kernel(PackWinoArgs p, 
 // TRACE (measurement only, sgmse_bench_conv): phase time stamps per workgroup (ConvArgs::trace; tools/analyze_trace.py).
 // ABL (measurement only, `make ABLATION=1`; results WRONG on purpose): 1 producer without the transcendental pair, 2 input transform without the
 // cross-lane shifts, 4 no LDS writes of the staged tile, 8 no staging at all behind the prologue, 16 no raw loads in the K loop, 32 the split arithmetic without its LDS stores.
-// SGMSE_WINO_PERSISTENT (`make persist`, a second library for a same-box comparison; NOT the product build): the kernel body below becomes
-// a per-tile function and the kernel a loop over tiles, one workgroup per CU -- see the end of this file.
-#ifdef SGMSE_WINO_PERSISTENT
-template <int ROWS, int ACT, int SC, int TRACE = 0, int ABL = 0>
-__device__ __forceinline__ void wino_tile(ConvArgs p, const int bx, const int nbx, const int by, const int tid_in) {
-#else
 template <int ROWS, int ACT, int SC, int TRACE = 0, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
-  const int bx = (int)blockIdx.x, nbx = (int)gridDim.x, by = (int)blockIdx.y, tid_in = (int)threadIdx.x;
-#endif
   using G = WinoGeom<ROWS>;
   using T = WinoTile<ROWS>;
   using S = SplitH2;
@@ -146,13 +138,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   u32x4* const s_in1 = s_all + G::STAGE_V;
   f32x4* const s_co = reinterpret_cast<f32x4*>(s_all + 2 * G::STAGE_V);
 
-  const int tid = tid_in;
+  const int tid = threadIdx.x;
   const int wave = drt_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
   const int cf = wave & 3, kh = wave >> 2;
   unsigned long long* trace = nullptr;
   if constexpr (TRACE) {
     if (tid == 0 && p.trace) {
-      trace = p.trace + 32 * (size_t)(by * nbx + bx);
+      trace = p.trace + 32 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
       trace[0] = (unsigned long long)drt_hw_id() | ((unsigned long long)drt_xcc_id() << 32);
       trace[1] = drt_clock();
     }
@@ -169,11 +161,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   const int tiles_xg = (p.W + 31) >> 5;
   const int tiles_y = (p.H + ROWS - 1) / ROWS;
   int b, ty, tx;
-  conv_tile_of(p, bx, nbx, tiles_xg, tiles_y, b, ty, tx);
+  conv_tile_of(p, (int)blockIdx.x, (int)gridDim.x, tiles_xg, tiles_y, b, ty, tx);
   if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
   const int H = p.H, W = p.W;
   const int tiles_x = (W + 31) >> 5;
-  const int co_blk = by;
+  const int co_blk = blockIdx.y;
   const int x0 = tx * 32, y0 = ty * ROWS;
   const unsigned HW = (unsigned)H * (unsigned)W;
 
@@ -522,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   if constexpr (TRACE) {
     if (trace) { trace[3] = drt_clock(); trace[6] = tbar; }
     if (tracer) {
-      unsigned long long* tq = p.trace + 32 * (size_t)(by * nbx + bx) + (tid == 0 ? 16 : 23);
+      unsigned long long* tq = p.trace + 32 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x) + (tid == 0 ? 16 : 23);
 #pragma unroll
       for (int i = 0; i < NTAP; ++i) tq[i] = ttap[i];
       tq[6] = tbar;
@@ -664,34 +656,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
     if (p.amax_out) {
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-      if (lane_e == 0) drt_atomic_max_nonneg(p.amax_out + b * kAmaxSpread + ((bx * 8 + wave) & (kAmaxSpread - 1)), vmax);
+      if (lane_e == 0) drt_atomic_max_nonneg(p.amax_out + b * kAmaxSpread + ((blockIdx.x * 8 + wave) & (kAmaxSpread - 1)), vmax);
     }
     DRT_CODE_MARKER(GUARD);
   };
   if (inside) finish(std::false_type{}); else finish(std::true_type{});
   if constexpr (TRACE) { if (trace) trace[4] = drt_clock(); }
 }
-
-#ifdef SGMSE_WINO_PERSISTENT
-// Persistent form (comparison build only): a workgroup works through the tiles bx = blockIdx.x, blockIdx.x + gridDim.x, ... of its
-// output-channel block (nbx tiles in all; gridDim.x == nbx is one tile per workgroup).  Two things keep the tile loop from costing
-// registers: the lane id is pinned per tile, so nothing derived from it is hoisted out of the loop and kept alive across the K loop; and the
-// arguments are re-read per tile from the kernel-argument segment through a pointer the compiler cannot see through -- as loop invariants
-// all ~70 dwords of them stay in SGPRs across the loop and spill into vector registers.  State at the end of round 4 (hipcc 7.2): no scalar
-// spills, the K loop spill-free, 47 / 50 spilled VGPRs around it in the 8-row shapes, none in the 4-row shape (202 VGPRs);
-// profiles/r04_wino_microbench_history.txt visit r04pw, DESIGN section 9.
-template <int ROWS, int ACT, int SC, int TRACE = 0, int ABL = 0>
-__global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p, int nbx) {
-#pragma unroll 1
-  for (int bx = blockIdx.x; bx < nbx; bx += gridDim.x) {
-    int tid = threadIdx.x;
-    DRT_PIN_INT(tid);
-    ConvArgs q;
-    DRT_KERNARG_COPY(q, p);
-    wino_tile<ROWS, ACT, SC, TRACE, ABL>(q, bx, nbx, (int)blockIdx.y, tid);
-    __syncthreads();                  // the next tile's prologue overwrites the LDS this tile's epilogue exchanged through
-  }
-}
-#endif
 
 }  // namespace sgmse

@@ -138,15 +138,6 @@ __device__ __forceinline__ void drt_wave_sync() { __builtin_amdgcn_fence(__ATOMI
 #define DRT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // pins 8 register pairs at this point of the program (pure arithmetic is otherwise free to sink below a later block)
 #define DRT_PIN8(a, b, c, d, e, f, g, h) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
-// dst = the kernel's FIRST argument `first_arg` (a trivially copyable struct), read again from the kernel-argument segment through an
-// opaque pointer: the compiler cannot treat the fields as values that are invariant across a loop around the use
-#define DRT_KERNARG_COPY(dst, first_arg) do { (void)(first_arg); \
-    typedef const __attribute__((address_space(4))) unsigned* drt_kp_t; \
-    drt_kp_t kp_ = (drt_kp_t)__builtin_amdgcn_kernarg_segment_ptr(); \
-    asm volatile("" : "+s"(kp_)); \
-    unsigned* qd_ = reinterpret_cast<unsigned*>(&(dst)); \
-    _Pragma("unroll") for (unsigned i_ = 0; i_ < sizeof(dst) / 4; ++i_) qd_[i_] = kp_[i_]; \
-  } while (0)
 #define DRT_PIN_INT(x) asm volatile("" : "+v"(x))
 #define DRT_CODE_MARKER(n) asm volatile("; code marker %0" ::"n"(n))
 #define DRT_LAUNCH(kern, grid, block, stream, ...) \

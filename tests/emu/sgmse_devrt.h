@@ -148,7 +148,6 @@ static inline void drt_wave_sync() { (void)emu::shfl_idx(0.f, 0); }
 #define DRT_PIN_HERE(x) ((void)0)
 #define DRT_SCHED_FENCE() ((void)0)
 #define DRT_PIN8(a, b, c, d, e, f, g, h) ((void)0)
-#define DRT_KERNARG_COPY(dst, first_arg) (dst) = (first_arg)
 #define DRT_PIN_INT(x) ((void)0)
 #define DRT_CODE_MARKER(n) ((void)0)
 #define DRT_LAUNCH(kern, grid, block, stream, ...) \

@@ -15,8 +15,9 @@
 #   ragged     tools/ragged_bench.py
 #   dirjob     tools/dir_job_bench.py
 #   lengths    bench.py --seconds sweep (utterance lengths off the 512-frame grid)
-#   libab      same-box A/B of TWO builds of the library: LIB_A, LIB_B (paths; default the product library and `make persist`'s), in
-#              the order A B B A: the kernel micro-benchmark (VARIANTS / SHAPES) and bench.py at batch 32 and batch 1
+#   libab      same-box A/B of TWO builds of the library: LIB_A (default: the product library) and LIB_B (a second build placed in the
+#              tree, e.g. from a scratch copy of csrc/), in the order A B B A: the kernel micro-benchmark (VARIANTS / SHAPES) and
+#              bench.py at batch 32 and batch 1
 # Everything lands in gpurun_out/ with the TAG prefix; copy what is to be judged into profiles/.
 set +e
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
@@ -121,7 +122,7 @@ if has lengths; then
   done
 fi
 if has libab; then
-  LIB_A=${LIB_A:-sgmse_amd/libsgmse_hip.so}; LIB_B=${LIB_B:-sgmse_amd/libsgmse_hip_persist.so}
+  LIB_A=${LIB_A:-sgmse_amd/libsgmse_hip.so}; LIB_B=${LIB_B:?libab needs LIB_B=<path of the second library>}
   : > $O/${TAG}_libab.txt
   runbench() { python -c "
 import sys, runpy
