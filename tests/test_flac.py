@@ -122,3 +122,43 @@ def test_the_enhancement_path_reads_flac_files(tmp_path):
         sys.path.remove(shims)
         for name in ("torchaudio", "soundfile"):
             sys.modules.pop(name, None)
+
+
+def test_random_streams_round_trip(tmp_path):
+    """Randomly drawn frame plans (subframe kinds, predictor orders, partition orders, both Rice widths, escapes, wasted bits, stereo
+    modes, block sizes, sample sizes) round-trip sample for sample; every stream carries its MD5, which the decoder verifies."""
+    g = np.random.default_rng(2024)
+    for trial in range(24):
+        bits = int(g.choice([8, 12, 16, 20, 24]))
+        nch = int(g.choice([1, 2]))
+        blocksize = int(g.choice([192, 256, 576, 1024, 1152]))
+        frames = int(g.integers(blocksize + 1, 3 * blocksize + 50))
+        x = _signal(frames, nch, bits, seed=trial, smooth=bool(g.integers(0, 2)))
+        plans = []
+        for _ in range(int(g.integers(1, 4))):
+            mode = str(g.choice(["independent", "left_side", "right_side", "mid_side"])) if nch == 2 else "independent"
+            subs = []
+            for _c in range(nch):
+                kind = str(g.choice(["fixed", "fixed", "lpc", "verbatim"]))
+                po = int(g.choice([0, 1, 2]))
+                if kind == "fixed":
+                    subs.append(dict(kind="fixed", order=int(g.integers(0, 5)), partition_order=po, rice2=bool(g.integers(0, 2)),
+                                     escape_first=bool(g.integers(0, 4) == 0)))
+                elif kind == "lpc":
+                    order = int(g.integers(1, 9))
+                    prec = int(g.integers(4, 13))
+                    coefs = [int(c) for c in g.integers(-(1 << (prec - 1)), 1 << (prec - 1), size=order)]
+                    subs.append(dict(kind="lpc", order=order, lpc=dict(coefs=coefs, shift=int(g.integers(prec - 2, prec + 3)), precision=prec),
+                                     partition_order=po, rice2=True))
+                else:
+                    subs.append(dict(kind="verbatim"))
+            plans.append({"stereo": mode, "sub": subs, "explicit_bits": bool(g.integers(0, 2))})
+        # partition orders must divide every block (the last, shorter one too) and leave room for the predictor's warm-up
+        last = frames % blocksize or blocksize
+        for pl in plans:
+            for sb in pl["sub"]:
+                if "partition_order" in sb:
+                    while sb["partition_order"] and (last % (1 << sb["partition_order"]) or blocksize % (1 << sb["partition_order"])
+                                                     or (last >> sb["partition_order"]) <= sb.get("order", 0)):
+                        sb["partition_order"] -= 1
+        _roundtrip(tmp_path, x, int(g.choice([8000, 16000, 44100, 48000])), bits, blocksize=blocksize, plans=plans)
