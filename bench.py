@@ -8,14 +8,22 @@ full 65.6 M-parameter NCSN++, fp32, random-init weights).  N > 1: one process pe
 rank enhances its own batch (weak scaling), the only collective is one weight broadcast before the timed region.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     dominant kernel = the 3x3 convolution of the wide U-Net levels (128-channel x 256-pixel tile): by default
-               the fp16x2 split kernel (fp32 operands as two fp16 terms, three partial products on the f16 MFMA pipe, fp32
-               accumulate; kernels_conv_split.h).  achieved = ALGORITHMIC fp32 FLOPs of its launches / their HIP-event time,
-               measured by one instrumented (eager) network evaluation on the same batch right after the timed region;
-               peak = the dense MFMA peak of the instruction used divided by the partial products per algorithmic
-               multiply: 2500/3 (fp16x2), 2500/6 (bf16x3), 157.3 (fp32 MFMA) TFLOP/s (MI355X_MICROARCH.md)
+  roofline     dominant kernel = the 3x3 convolution of the wide U-Net levels.  By default that is conv3x3_wino_kernel
+               (kernels_conv_wino.h): 1-D Winograd F(2,3) along the frame axis on top of the fp16x2 operand split (fp32
+               operands as two fp16 terms, three partial products on the f16 MFMA pipe, fp32 accumulate).  achieved =
+               ALGORITHMIC fp32 FLOPs of its launches / their HIP-event time, measured by one instrumented (eager)
+               network evaluation on the same batch right after the timed region; peak = the ceiling of THE FORM THAT
+               RUNS: dense f16 MFMA peak / MFMA multiplies issued per algorithmic multiply = 2500/2 (Winograd fp16x2: 12
+               K-steps per output pair where the direct form has 18, x 3 partial products), 2500/3 (direct fp16x2),
+               2500/6 (bf16x3), 157.3 (fp32 MFMA) TFLOP/s (MI355X_MICROARCH.md) -- so frac <= 1 by construction;
+               frac_of_the_direct_form keeps the 2500/3 yardstick of rounds 1-4 beside it.  traffic / mfma_busy: PMC
+               passes of THIS command at batch 32 when profiles/ holds them (tools/gpu_visit.sh STEPS=pmcbench)
   cpu_baseline the CPU oracle (oracle/, a torch-fp32 restatement of the reference) timed on this box's host cores on
                a bounded sample, extrapolated to the 60-evaluation run
+  other_workloads  configs[2], configs[3], batch 1, and configs[1] again under SGMSE_CONV_SPLIT=0 (exact fp32 MFMA
+               everywhere: the arithmetic of the reference itself, BASELINE.md section 3's ceiling applies to it)
+  parity       rel. L2 of this build against the reference's own run of configs[1] (tests/golden/pc16k_full.npz, one
+               utterance, replayed noise) under the default kernels and under SGMSE_CONV_SPLIT=0
 """
 import argparse
 import json
@@ -37,13 +45,13 @@ DOMINANT = {   # conv split mode -> (kernel, effective peak, how the peak is der
         MFMA16_PEAK_TFLOPS / 6, "dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per multiply", "void sgmse::conv3x3_split_kernel<sgmse::SplitB3, 0, 1, 0"),
     2: ("conv3x3_split_kernel<SplitH2> (3x3 implicit GEMM, fp16x2 operand split, 3 partial products, fp32 accumulate)",
         MFMA16_PEAK_TFLOPS / 3, "dense f16 MFMA peak 2500 TFLOP/s / 3 partial products per multiply", "void sgmse::conv3x3_split_kernel<sgmse::SplitH2, 0, 1, 0"),
-    # split mode 2 with the Winograd kernel on the wide levels (the default since round 4).  `peak` stays the ceiling of the DIRECT form
-    # -- what an algorithmic multiply costs on this pipe without the transform, the yardstick of rounds 1-3 -- and the line also carries
-    # the ceiling of the form that actually runs (F(2,3) along T: 12 instead of 18 K-steps per output pair, i.e. 2 MFMA multiplies per
-    # algorithmic multiply instead of 3)
+    # split mode 2 with the Winograd kernel on the wide levels (the default since round 4).  `peak` is the ceiling of the form that
+    # actually runs (F(2,3) along T: 12 instead of 18 K-steps per output pair, i.e. 2 MFMA multiplies per algorithmic multiply instead
+    # of 3), so `frac` is a real fraction; the direct form's 2500/3 (the yardstick of rounds 1-4) rides along as frac_of_the_direct_form
     3: ("conv3x3_wino_kernel<8,...> (3x3 implicit GEMM, 1-D Winograd F(2,3) along T x fp16x2 operand split, fp32 accumulate; the levels "
         "below 64 x 128 stay on conv3x3_split_kernel<SplitH2>)",
-        MFMA16_PEAK_TFLOPS / 3, "dense f16 MFMA peak 2500 TFLOP/s / 3 partial products per algorithmic multiply (direct form)",
+        MFMA16_PEAK_TFLOPS / 2, "dense f16 MFMA peak 2500 TFLOP/s / 2 MFMA multiplies per algorithmic multiply (3 partial products x 12/18 "
+                                "K-steps of the F(2,3) form)",
         "void sgmse::conv3x3_wino_kernel<8, 1, 0"),
 }
 HBM_PEAK_GBS = 8000.0
@@ -73,9 +81,10 @@ def parse():
 
 
 class PowerSampler:
-    """Socket power and shader clock from rocm-smi, sampled in a background thread during the timed region (rank 0, N = 1).  The
-    dominant kernel runs AT the socket power cap (profiles/r02_power_probe.txt): its clock -- and with it the achievable share
-    of the nominal MFMA peak -- is set by energy per tile, which is what this evidence is for."""
+    """Socket power and shader clock from rocm-smi, sampled in a background thread during the timed region (rank 0, N = 1).
+    Evidence for the clock the path actually ran at: the direct fp16x2 kernel of rounds 2-3 sat at the 1400 W cap at 1.5-1.7 GHz
+    (profiles/r02_power_probe.txt); the Winograd kernel runs below the cap at 1.9-2.0 GHz (profiles/r04_power_probe.txt), and the
+    share of the NOMINAL (2.4 GHz) MFMA peak in `roofline` is bounded by that clock too."""
 
     def __init__(self, period=0.5):
         import threading
@@ -181,7 +190,10 @@ def cpu_baseline(state, n_evals, N, snr, frames=512):
             "sample": f"{n_evals} timed NCSN++ evaluations at [1,4,256,{frames}] after 1 warm-up, scaled x{512 // frames} to the "
                       f"512-frame utterance ({t_eval:.2f} s per full evaluation on {cores} threads) + front-end + one PC step of "
                       f"sampler glue, extrapolated to {2 * N} evaluations; B=1, 4 s utterance",
-            "seconds_per_eval": t_eval, "rtf": per_utt / 4.0}
+            "seconds_per_eval": t_eval, "rtf": per_utt / 4.0,
+            "port_vs_reference": "calibration from the build container (8 threads, same [1,4,256,512] evaluation, interleaved runs): the imported "
+                                 "reference NCSNpp takes 3.07 s per evaluation, this port 2.33 s -- the port is 1.32x FASTER than the reference "
+                                 "module it restates (no autograd bookkeeping, fused padding), so the reference's own CPU rate is about value / 1.32"}
 
 
 def hbm_traffic_of_dominant_kernel(prefix):
@@ -198,6 +210,61 @@ def hbm_traffic_of_dominant_kernel(prefix):
                 note = f"{os.path.basename(f)}: 3x3 128->128 @256x512, B=8, fused producer+residual epilogue, median {v.get('median_duration_us_under_pmc')} us under the counters"
                 return v["hbm_bytes_per_launch"], note + (f"; algorithmic bytes of that launch = {alg:.4g}" if alg else "")
     return None, "no committed PMC profile holds the dominant kernel"
+
+
+def pmc_of_the_bench_run(prefix, batch):
+    """Counters of THIS command's own launches of the dominant kernel (tools/gpu_visit.sh STEPS=pmcbench: rocprofv3 --pmc passes over
+    `bench.py --steps 1 --warmup 1 --no-others --no-cpu-baseline --no-profile` at the benched batch, one pass per counter group,
+    summarised by tools/summarize_pmc_bench.py into profiles/*pmc_bench_b<batch>.json).  When the file is there, `traffic` is its
+    FETCH_SIZE + WRITE_SIZE per launch (mean over the dominant kernel's launches of the run) and `mfma_busy` its
+    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE); otherwise the micro-benchmark figures stay and say so."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_bench_b{batch}.json")))
+    if not files:
+        return {}
+    d = json.load(open(files[-1]))
+    row = next((v for k, v in d.items() if k.startswith(prefix.replace("void ", ""))), None)
+    if not row:
+        return {}
+    upd = {"pmc_source": f"{os.path.basename(files[-1])}: rocprofv3 --pmc passes over this command at batch {batch} "
+                         f"({row.get('launches')} launches of the dominant kernel instantiation)"}
+    if row.get("hbm_bytes_per_launch") is not None:
+        upd["traffic"] = row["hbm_bytes_per_launch"]
+        upd["traffic_source"] = upd["pmc_source"]
+        upd["traffic_note"] = (f"FETCH_SIZE + WRITE_SIZE per launch, mean over the run's launches; algorithmic bytes per launch (mean) "
+                               f"{row.get('algorithmic_bytes_per_launch')}")
+    for k in ("mfma_busy", "effective_clock_ghz", "valu_per_mfma", "lds_conflict_frac"):
+        if row.get(k) is not None:
+            upd[k] = row[k]
+    return upd
+
+
+def parity_leg(env):
+    """CHECKER LEG (like cpu_baseline: the only other place this script touches oracle/ and tests/): configs[1] on ONE utterance with
+    replayed noise against the reference's own run (tests/golden/pc16k_full.npz, written by oracle/make_golden_full.py from the imported
+    reference), under the default kernels and under SGMSE_CONV_SPLIT=0 (exact fp32 MFMA everywhere).  ~3 s of GPU time."""
+    tests = os.path.join(ROOT, "tests")
+    if tests not in sys.path:
+        sys.path.insert(0, tests)
+    import parity as TP
+    res = {"fixture": "tests/golden/pc16k_full.npz (the reference's NCSNpp + OUVESDE + pc_sampler, 60 NFE, one 4 s utterance, replayed noise)",
+           "gate": {"spectrogram": TP.SAMPLER_TOL, "waveform": TP.WAVE_TOL}}
+    saved = os.environ.get("SGMSE_CONV_SPLIT")
+    try:
+        for key, mode in (("default kernels", None), ("SGMSE_CONV_SPLIT=0 (exact fp32 MFMA everywhere)", "0")):
+            if mode is None:
+                os.environ.pop("SGMSE_CONV_SPLIT", None)
+                if saved is not None:
+                    os.environ["SGMSE_CONV_SPLIT"] = saved
+            else:
+                os.environ["SGMSE_CONV_SPLIT"] = mode
+            e_spec, e_wave, nfe = TP.run_full_config(str(env.dev), "pc16k_full")
+            res[key] = {"rel_l2_spectrogram": e_spec, "rel_l2_waveform": e_wave, "nfe": nfe}
+    finally:
+        os.environ.pop("SGMSE_CONV_SPLIT", None)
+        if saved is not None:
+            os.environ["SGMSE_CONV_SPLIT"] = saved
+    return res
 
 
 WORKLOADS = {
@@ -318,7 +385,8 @@ def measure(env, a, workload, batch, steps, warmup, sampler=None, N=None, snr=No
                    else f"utterances/sec, {wl['backbone']} {sampler.upper()} N={N}, {wl['sr'] // 1000} kHz {seconds:g} s utterances"),
         "value": utts / elapsed, "unit": "utterances/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": {0: "f32", 1: "f32 (bf16x3-split products, fp32 accumulate)",
+                  2: "f32 (fp16x2-split products, fp32 accumulate)"}[ctx.conv_split_mode()],
         "dtype_note": {0: "exact fp32 MFMA everywhere",
                        1: "fp32 operands and accumulation; wide 3x3 / 1x1 conv products formed from exact 3-way bf16 operand splits on the bf16 MFMA pipe",
                        2: "fp32 operands and accumulation; wide 3x3 / 1x1 conv products formed from fp16x2 operand splits (exact per-utterance power-of-two "
@@ -364,8 +432,9 @@ def measure(env, a, workload, batch, steps, warmup, sampler=None, N=None, snr=No
                            "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),
                            "flop_per_launch_avg": dom["work"] / max(dom["launches"], 1)}
         if wino:
-            out["roofline"]["peak_of_the_winograd_form"] = MFMA16_PEAK_TFLOPS / 2
-            out["roofline"]["frac_of_the_winograd_form"] = ach / (MFMA16_PEAK_TFLOPS / 2)
+            out["roofline"]["peak_of_the_direct_form"] = MFMA16_PEAK_TFLOPS / 3
+            out["roofline"]["frac_of_the_direct_form"] = ach / (MFMA16_PEAK_TFLOPS / 3)
+        out["roofline"].update(pmc_of_the_bench_run(prefix, batch))
         classes = {}
         for k, v in prof.items():
             rate = v["work"] / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
@@ -393,18 +462,34 @@ def main():
         del model
         import gc
         others = {}
-        for key, (wname, batch, steps) in {"configs[2] ode16k": ("ode16k", 32, 1), "configs[3] pc48k": ("pc48k", 16, 1),
-                                           "configs[0] shape on the GPU: pc16k batch 1 (per-file loop of enhancement.py)": ("pc16k", 1, 3)}.items():
+        exact_key = "configs[1] under SGMSE_CONV_SPLIT=0: exact fp32 MFMA everywhere (the reference's own arithmetic; BASELINE.md section 3's ceiling)"
+        for key, (wname, batch, steps, envs) in {
+                "configs[2] ode16k": ("ode16k", 32, 1, {}), "configs[3] pc48k": ("pc48k", 16, 1, {}),
+                "configs[0] shape on the GPU: pc16k batch 1 (per-file loop of enhancement.py)": ("pc16k", 1, 3, {}),
+                exact_key: ("pc16k", 32, 1, {"SGMSE_CONV_SPLIT": "0"})}.items():
             gc.collect()
             env.torch.cuda.empty_cache()
+            saved = {k: os.environ.get(k) for k in envs}
+            os.environ.update(envs)                       # (the engine re-reads its switches when a model is built)
             try:
                 o, m = measure(env, a, wname, batch, steps, 1)
                 del m
-                others[key] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "rtf", "steps", "warmup", "config", "roofline",
+                others[key] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "rtf", "steps", "warmup", "dtype", "config", "roofline",
                                                  "kernel_classes_one_eval", "graph_captures_rank0") if k in o}
             except Exception as e:      # noqa: BLE001 -- the headline stands on its own
                 others[key] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                for k, v in saved.items():
+                    os.environ.pop(k, None)
+                    if v is not None:
+                        os.environ[k] = v
         out["other_workloads"] = others
+        gc.collect()
+        env.torch.cuda.empty_cache()
+        try:
+            out["parity"] = parity_leg(env)
+        except Exception as e:          # noqa: BLE001
+            out["parity"] = {"error": f"{type(e).__name__}: {e}"}
     if env.rank == 0:
         print(json.dumps(out), flush=True)
     if env.world > 1:

@@ -552,8 +552,11 @@ class Engine {
     ConvPlan pl = choose_conv_plan(ks, Cin, Cout, H, W);
     if (force_direct == 6) {                               // exact-fp32 VALU kernel of the C -> 4 pyramid convolutions
       SG_REQUIRE(conv_thin_eligible(ks, a.C1, C2, Cout), "op_conv2d: shape is not eligible for the thin-output kernel");
-      a.w = pack_thin(w_oihw, Cin, Cout, false);
+      const float* pk = pack_thin(w_oihw, Cin, Cout, false);
+      a.w = pk;
       launch_conv_thin(a, stream_);
+      SG_CHECK(drt::stream_sync(stream_));
+      free_tmp(const_cast<float*>(pk));
     } else if (force_direct == 4 || force_direct == 5) {          // Winograd F(2,3) x fp16x2: 4 = 8-row shape, 5 = 4-row shape
       SG_REQUIRE(ks == 3 && conv_wino_eligible(a.C1, C2, Cout, W), "op_conv2d: shape is not eligible for the Winograd kernel");
       const float* pk = pack_wino(w_oihw, Cin, Cout, false, &a.co_scale);
@@ -1395,7 +1398,8 @@ class Engine {
     // the C -> 4 convolutions of the output pyramid: exact-fp32 VALU kernel (kernels_conv_thin.h) -- on the matrix pipe
     // seven eighths of their work was padding (decided by the layer's shape and U-Net level alone: never by batch or utterance length)
     // (the two finest levels: below them a launch at batch 1 has few 16 x 64 tiles and their 32-64 serial stages are slower than the MFMA path's split-K)
-    const bool use_thin = w.packed_thin && conv_thin_eligible(w.ks, a.C, b ? b->C : 0, w.cout) && !emit_stats && level_of(a.H) <= 1;
+    // (conv3x3_thin_kernel has no time-embedding row, accumulator scale or folded shortcut: a layer that carries one stays on the MFMA shapes)
+    const bool use_thin = w.packed_thin && conv_thin_eligible(w.ks, a.C, b ? b->C : 0, w.cout) && !emit_stats && level_of(a.H) <= 1 && !bias2 && !sc;
     if (use_thin) {
       ca.w = w.packed_thin; ca.stats_out = nullptr;
       launch_conv_thin(ca, stream_);
@@ -1417,9 +1421,12 @@ class Engine {
         launch_conv_split(ca, w.ks, w.split_mode, stream_, rows4, 0, ksplit);
       }
       if (coarse_split && partial) arena_.release(partial);
-      if (noting())
+      if (noting()) {
+        char scn[24] = "";
+        if (sc) snprintf(scn, sizeof scn, " +shortcut(%d)", ca.sc_C1 + ca.sc_C2);      // (input channels of the folded 1x1)
         snprintf(prof_note_, sizeof prof_note_, "conv3x3-%s %d->%d @%dx%dx%d%s%s%s%s", use_wino ? "wino" : "split", Cin, w.cout, B_, a.H, a.W, res ? " +res" : "",
-                 xf.scale ? " +gn" : "", sc ? " +shortcut" : "", ca.rag_cols ? " existing-tiles" : "");
+                 xf.scale ? " +gn" : "", scn, ca.rag_cols ? " existing-tiles" : "");
+      }
       tick(w.ks == 3 ? (w.cout >= 128 ? TC_CONV3_BIG : TC_CONV3) : TC_CONV1, fl);
     } else if (use_mfma) {
       ConvPlan pl{co_t, rows_, true};

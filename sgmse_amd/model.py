@@ -265,6 +265,10 @@ class ScoreModel(nn.Module):
         return make(y, kwargs) if minibatch is None else self._chunked(make, y, minibatch, kwargs)
 
     def get_ode_sampler(self, y, N=None, minibatch=None, **kwargs):
+        """reference model.py:370-390.  ``denoise=False`` (the only setting under which the reference's function completes) selects the
+        reference's adaptive scipy solver -- host round trips, ``seed`` / ``use_graph`` / ``streams`` / ``N`` do not apply (a warning says
+        so); the default runs the fused fixed-step probability-flow loop.  ``adaptive=True/False`` chooses explicitly
+        (sampling.get_ode_sampler)."""
         sde = self.sde.copy()
         sde.N = self.sde.N if N is None else N
         kwargs = {"eps": self.t_eps, **kwargs}

@@ -160,6 +160,11 @@ def get_ode_sampler(sde, score_fn, y, inverse_scaler=None, denoise=True, rtol=1e
     if adaptive is None:
         adaptive = denoise is False
     if adaptive:
+        dropped = [k for k, v in (("seed", seed), ("streams", streams)) if v is not None] + ([] if use_graph else ["use_graph"])
+        if dropped:
+            warnings.warn(f"get_ode_sampler(adaptive solver): {', '.join(dropped)} do not apply -- scipy's solve_ivp drives one network "
+                          f"evaluation per call through host memory (no captured loop); the prior draw comes from `noise` or torch's global "
+                          f"generator, and sde.N is ignored as in the reference.  Pass adaptive=False for the fused fixed-step loop")
         return _adaptive_ode_sampler(sde, score_fn, y, inverse_scaler, denoise, rtol, atol, method, eps, device, noise, kwargs)
     ignored = [k for k, v, d in (("rtol", rtol, 1e-5), ("atol", atol, 1e-5), ("method", method, "RK45"), ("denoise", denoise, True),
                                  ("inverse_scaler", inverse_scaler, None)) if v != d]

@@ -564,11 +564,12 @@ def check_enhance(dev, L=8000, N=2):
     assert nfe == 2 * N and rel_l2(xb[0].cpu(), x_ref) < WAVE_TOL
 
 
-def check_full_config(dev, name):
+def run_full_config(dev, name):
     """A BASELINE.json configuration itself, one utterance, against the REFERENCE's own output (fixture written by
     oracle/make_golden_full.py from the reference's full-width network, OUVESDE and pc_sampler with replayed noise):
-    full-width network x full utterance x full N, through the batched entry point; gates: sampled spectrogram <= 1e-4,
-    enhanced waveform <= 1e-3 (north star).  Inputs are rebuilt from seeds (oracle/full_cases.py)."""
+    full-width network x full utterance x full N, through the batched entry point.  Inputs are rebuilt from seeds
+    (oracle/full_cases.py).  Returns (rel. L2 of the sampled spectrogram, of the enhanced waveform, NFE); also called by
+    bench.py's parity leg, which reports the two figures of the benched build in the driver's line."""
     from oracle.full_cases import FULL_CASES, front_cfg
     c = FULL_CASES[name]
     z = load(name)
@@ -593,8 +594,14 @@ def check_full_config(dev, name):
     setattr(m, "get_pc_sampler" if c["sampler"] == "pc" else "get_ode_sampler", spy)
     x_hat, nfe = m.enhance_batch(y.to(dev), N=c["N"], snr=c["snr"], sampler_type=c["sampler"], noise=noise, pad_mode=c["pad"])
     e_spec, e_wave = rel_l2(got["spec"].cpu(), z["spec"]), rel_l2(x_hat[0].cpu(), z["wave"])
-    print(f"{name} on {dev}: {nfe} NFE, rel_l2 vs the reference: spectrogram {e_spec:.3e}, waveform {e_wave:.3e}")
     assert nfe == int(z["nfe"]) and got["spec"].shape == z["spec"].shape
+    return e_spec, e_wave, nfe
+
+
+def check_full_config(dev, name):
+    """run_full_config with the gates: sampled spectrogram <= 1e-4, enhanced waveform <= 1e-3 (north star)."""
+    e_spec, e_wave, nfe = run_full_config(dev, name)
+    print(f"{name} on {dev}: {nfe} NFE, rel_l2 vs the reference: spectrogram {e_spec:.3e}, waveform {e_wave:.3e}")
     assert e_spec < SAMPLER_TOL and e_wave < WAVE_TOL, (name, e_spec, e_wave)
 
 

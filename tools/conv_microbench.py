@@ -21,6 +21,12 @@ ALL_SHAPES = [  # ks, B, Cin, Cout, H, W
     (3, 8, 256, 128, 256, 512),
     (3, 16, 256, 256, 64, 128),
     (1, 8, 256, 128, 256, 512),
+    # the same 128->128 layer with the same tile count (4096) on smaller planes, and at the benched batch: what the per-FLOP deficit of
+    # the 256 x 512 level against 128 x 256 in the network follows -- plane size or launch length
+    (3, 32, 128, 128, 128, 256),
+    (3, 32, 128, 128, 256, 512),
+    (3, 128, 128, 128, 64, 128),
+    (3, 2, 128, 128, 256, 512),
 ]
 SHAPES = [ALL_SHAPES[int(i)] for i in os.environ.get("SHAPES", "0,1,2,3").split(",")]
 FUSED = [int(v) for v in os.environ.get("FUSED", "0,1").split(",")]

@@ -11,6 +11,8 @@
 #   bench      bench.py with the driver's defaults -> ${TAG}_bench_b32.json
 #   rocprof    rocprofv3 --kernel-trace --stats of the bench command -> ${TAG}_bench_b32_kernel_stats.csv
 #   pmc        PMC passes of the dominant kernel's micro-benchmark (tools/conv_microbench.py) -> ${TAG}_pmc_*.json, ${TAG}_hbm_traffic_*.json
+#   pmcbench   PMC passes over the bench command itself at batch 32 (counters of the run's own launches of the dominant kernel)
+#              -> ${TAG}_pmc_bench_b32.json (bench.py reads it: roofline.traffic, roofline.mfma_busy)
 #   dumps      per-launch timings of one evaluation at batch 32 and batch 1
 #   ragged     tools/ragged_bench.py
 #   dirjob     tools/dir_job_bench.py
@@ -103,6 +105,31 @@ for f in ("$O/${TAG}_pmc_conv.json", "$O/${TAG}_hbm_traffic.json"):
     except Exception as e: print(f, "FAILED", e)
 PY
   rm -rf $O/pmc/*/ 2>/dev/null
+fi
+if has pmcbench; then
+  # counters of the bench command's OWN launches at the benched batch: one rocprofv3 --pmc pass per counter group
+  # (--kernel-trace only beside it), filtered to the Winograd kernel; PMCB_ARGS adds bench flags (e.g. --no-graph when the replayed
+  # graph does not survive the counters); the per-launch listing of the same batch gives the algorithmic bytes
+  rm -rf $O/pmcb; mkdir -p $O/pmcb
+  PB=${PMCB_BATCH:-32}
+  echo "== PMC passes over bench.py --batch $PB (PMCB_ARGS=$PMCB_ARGS)"
+  for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
+    n=$(echo $grp | cut -d' ' -f1)
+    timeout ${PMCB_TIMEOUT:-420} rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "${PMCB_REGEX:-conv3x3_wino_kernel}" --output-format csv -d $O/pmcb/$n -o pmc -- \
+      python bench.py --batch $PB --steps 1 --warmup 1 --no-others --no-cpu-baseline --no-profile $PMCB_ARGS > $O/pmcb/$n.log 2>&1
+    rc=$?; echo "pmcbench pass [$grp] rc=$rc; bench line: $(grep -o '"value": [0-9.]*' $O/pmcb/$n.log | head -1)"
+    [ $rc -ne 0 ] && tail -5 $O/pmcb/$n.log | cut -c1-300
+  done
+  SGMSE_PROFILE_DUMP=1 timeout 300 python bench.py --batch $PB --N 2 --steps 1 --warmup 1 --no-cpu-baseline --no-others > /dev/null 2> $O/pmcb/dump.txt
+  python tools/summarize_pmc_bench.py $O/pmcb/SQ_VALU_MFMA_BUSY_CYCLES $O/pmcb/SQ_LDS_BANK_CONFLICT $O/pmcb/FETCH_SIZE $O/pmcb/WRITE_SIZE --dump $O/pmcb/dump.txt > $O/${TAG}_pmc_bench_b${PB}.json 2>$O/pmcb/summ.err
+  python - <<PY
+import json
+try:
+    d = json.load(open("$O/${TAG}_pmc_bench_b${PB}.json"))
+    for k, v in d.items(): print(k[:70], {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a != "counters_mean"})
+except Exception as e: print("pmcbench summary FAILED", e)
+PY
+  rm -rf $O/pmcb/*/ 2>/dev/null
 fi
 if has dumps; then
   echo "== per-launch timings of one evaluation (batch 32 and batch 1)"
