@@ -528,6 +528,28 @@ def test_bench_under_the_drivers_torch_distributed_run_line(emu):
     assert d["weight_broadcast_ms"] > 0 and d["scaling"] == "weak"
 
 
+def test_bench_at_eight_ranks_prints_one_line_for_the_whole_job(emu):
+    """The driver's 8-GPU scaling run, rehearsed: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8`
+    (CPU tensors, gloo, emulator, reduced-width network).  Exactly one JSON line, from rank 0; n_gpus = 8; eight per-rank rates;
+    value = all ranks' utterances over the slowest rank's time; no rank prints a second line or a power / cpu_baseline object."""
+    import json
+    from conftest import EMU_LIB
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(SGMSE_EMU_THREADS="1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", "29591", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+                          "--batch", "1", "--seconds", "0.5", "--N", "1", "--test-emulator", EMU_LIB],
+                         capture_output=True, text=True, timeout=2400, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-3000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["collective_backend"]["world_size"] == 8 and len(d["per_rank_utt_per_s"]) == 8
+    assert d["scaling"] == "weak" and d["config"]["batch_per_gpu"] == 1 and d["weight_broadcast_ms"] > 0
+    assert abs(d["value"] - 8 * 1 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]          # whole-job aggregate over the slowest rank
+    assert min(d["per_rank_utt_per_s"]) * 8 <= d["value"] * (1 + 1e-6)
+    assert "cpu_baseline" not in d and "power" not in d and "other_workloads" not in d        # rank-0-at-N=1-only legs stay out
+
+
 def test_assign_files_balances_by_padded_frames():
     """--balance frames: longest-processing-time assignment by padded frame count; a partition of the file list that every rank
     computes identically; --balance contiguous is the reference's split (model.py:212-223)."""
