@@ -7,9 +7,6 @@
 #include "kernels_conv_wino.h"
 #include "kernels_conv_thin.h"
 
-#ifndef SGMSE_WINO_W4_DEFAULT
-#define SGMSE_WINO_W4_DEFAULT 0        // 8-row tiles from which a Winograd launch takes the 4-wave shape (0: never); see Engine::read_knobs
-#endif
 #ifndef SGMSE_CONV_SPLIT_DEFAULT
 #define SGMSE_CONV_SPLIT_DEFAULT 2     // 0: fp32 MFMA everywhere, 1: bf16x3 on the wide levels, 2: fp16x2 on the wide levels
 #endif
@@ -169,16 +166,8 @@ inline void launch_conv_split(const ConvArgs& a, int ks, int mode, drt::stream_t
 inline bool conv_wino_eligible(int C1, int C2, int Cout, int W) {
   return Cout % 128 == 0 && (C1 + C2) % 16 == 0 && (C2 == 0 || C1 % 16 == 0) && (C1 + C2) <= 512 && W % 2 == 0;
 }
-// w4: the 4-wave shape (128 co x 4 rows x 32 px per 256-thread workgroup, two workgroups per CU) for launches that fill the chip.
-inline void launch_conv_wino(const ConvArgs& a, drt::stream_t st, bool rows4, bool trace = false, int abl = 0, bool w4 = false) {
+inline void launch_conv_wino(const ConvArgs& a, drt::stream_t st, bool rows4, bool trace = false, int abl = 0) {
   const bool act = a.in_scale && a.in_act;
-  if (w4) {
-    const dim3 grid(conv_grid_tiles(a, 4), a.Cout / 128, 1);
-    if (a.sc_w) DRT_LAUNCH((conv3x3_wino4w_kernel<1, 1>), grid, dim3(256), st, a);
-    else if (act) DRT_LAUNCH((conv3x3_wino4w_kernel<1, 0>), grid, dim3(256), st, a);
-    else DRT_LAUNCH((conv3x3_wino4w_kernel<0, 0>), grid, dim3(256), st, a);
-    return;
-  }
 #ifdef SGMSE_ABLATION_FULL
 #define SGMSE_WABL_CASE(V) if (abl == V) { DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0, 0, V>), dim3(conv_grid_tiles(a, 8), a.Cout / 128, 1), dim3(512), st, a); return; }
   SGMSE_WABL_CASE(1) SGMSE_WABL_CASE(2) SGMSE_WABL_CASE(4) SGMSE_WABL_CASE(8) SGMSE_WABL_CASE(16) SGMSE_WABL_CASE(24) SGMSE_WABL_CASE(3) SGMSE_WABL_CASE(32) SGMSE_WABL_CASE(20)

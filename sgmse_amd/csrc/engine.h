@@ -557,7 +557,7 @@ class Engine {
       launch_conv_thin(a, stream_);
       SG_CHECK(drt::stream_sync(stream_));
       free_tmp(const_cast<float*>(pk));
-    } else if (force_direct == 4 || force_direct == 5 || force_direct == 7) {   // Winograd F(2,3) x fp16x2: 4 = 8-row shape, 5 = 4-row shape, 7 = 4-wave shape
+    } else if (force_direct == 4 || force_direct == 5) {          // Winograd F(2,3) x fp16x2: 4 = 8-row shape, 5 = 4-row shape
       SG_REQUIRE(ks == 3 && conv_wino_eligible(a.C1, C2, Cout, W), "op_conv2d: shape is not eligible for the Winograd kernel");
       const float* pk = pack_wino(w_oihw, Cin, Cout, false, &a.co_scale);
       a.w = pk;
@@ -565,7 +565,7 @@ class Engine {
       const float* am2 = x2 ? bounds + (size_t)B * kAmaxSpread : nullptr;
       float* xb = producer_bound(in_scale, in_shift, Cin, bounds, am2, B);
       a.xbound = xb;
-      launch_conv_wino(a, stream_, force_direct == 5, false, 0, force_direct == 7);
+      launch_conv_wino(a, stream_, force_direct == 5);
       SG_CHECK(drt::stream_sync(stream_));
       free_tmp(const_cast<float*>(pk)); free_tmp(bounds); free_tmp(xb);
     } else if (force_direct == 2 || force_direct == 3) {          // the split kernels: 2 bf16x3, 3 fp16x2
@@ -685,8 +685,7 @@ class Engine {
       if (!(variant & (64 | 128))) { ablate = abl_split & 15; abl_split = 0; }   // fp32 kernels: run-time ablation bits 12..15
       variant &= 4095;
     }
-    const bool wino = variant >= 0 && (variant & 1024);          // measurement: the Winograd F(2,3) x fp16x2 kernel (bit 23: its 4-row shape, bit 11: its 4-wave shape)
-    const bool wino_w4 = wino && (variant & 2048);
+    const bool wino = variant >= 0 && (variant & 1024);          // measurement: the Winograd F(2,3) x fp16x2 kernel (bit 23: its 4-row shape)
     const int smode = variant < 0 ? 0 : ((variant & 128) ? 2 : ((variant & 64) ? 1 : 0));
     const bool b3 = smode != 0 && !wino;
     SG_REQUIRE(!wino || (ks == 3 && conv_wino_eligible(Cin, 0, Cout, W)), "bench_conv: shape is not eligible for the Winograd kernel");
@@ -739,7 +738,7 @@ class Engine {
       a.trace = trace_dev;
     }
     auto go = [&]() {
-      if (wino) launch_conv_wino(a, stream_, split_rows4, (abl_split & 64) != 0, abl_split & 63, wino_w4);
+      if (wino) launch_conv_wino(a, stream_, split_rows4, (abl_split & 64) != 0, abl_split & 63);
       else if (b3) launch_conv_split(a, ks, smode, stream_, split_rows4, abl_split);
       else launch_conv_mfma(a, ks, pl, stream_, variant);
     };
@@ -1417,10 +1416,7 @@ class Engine {
       if (coarse_split) { ca.kchunk_stages = kchunk; ca.partial = partial; }
       if (use_wino) {
         ca.w = w.packed_wino; ca.co_scale = w.wino_scale; ca.acc_scale = nullptr;
-        // one 512-thread workgroup per CU: the 8-row shape from two rounds of the chip; the 4-wave shape (two 256-thread workgroups per
-        // CU) where the launch fills the chip several times over (SGMSE_WINO_W4: minimum number of 8-row tiles, 0 = never)
-        const bool w4 = wino_w4_min_ > 0 && nblk8 >= wino_w4_min_;
-        launch_conv_wino(ca, stream_, nblk8 < tile_min_blocks_, false, 0, w4);
+        launch_conv_wino(ca, stream_, nblk8 < tile_min_blocks_);   // one 512-thread workgroup per CU: the 8-row shape from two rounds of the chip
       } else {
         launch_conv_split(ca, w.ks, w.split_mode, stream_, rows4, 0, ksplit);
       }
@@ -1793,8 +1789,6 @@ class Engine {
     split_min_tiles_ = e ? atol(e) : 8L;                 // per-image 8x32 tiles from which a layer uses a split kernel (profiles/r01_b3_threshold.txt)
     e = getenv("SGMSE_WINO_MIN_TILES");
     wino_min_tiles_ = e ? atol(e) : 32L;                 // ... and the Winograd kernel (32: the 64 x 128 level and up)
-    e = getenv("SGMSE_WINO_W4");
-    wino_w4_min_ = e ? atol(e) : SGMSE_WINO_W4_DEFAULT;  // launches of at least this many 8-row tiles take the 4-wave shape of the Winograd kernel (0: none)
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue (0: stand-alone statistics passes)
     poison_ = flag("SGMSE_POISON", false);               // NaN patterns in every allocation and in the arena before every forward
   }
@@ -1814,7 +1808,7 @@ class Engine {
   static constexpr bool coarse_chunked_ = true, fold_shortcut_ = true, coarse_split_ = true, entry_mfma_ = true;
   ConvW entry8_{}; int entry8_idx_ = -1;
   bool poison_ = false, debug_sync_ = false, conv_xcd_map_ = true, rag_prefix_ = true, wino_ = true;
-  long wino_min_tiles_ = 32, wino_w4_min_ = SGMSE_WINO_W4_DEFAULT;
+  long wino_min_tiles_ = 32;
   static constexpr long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8;      // (profiles/r02_chunk_splitk.txt)
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;

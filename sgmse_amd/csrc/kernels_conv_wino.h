@@ -664,423 +664,4 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
   if constexpr (TRACE) { if (trace) trace[4] = drt_clock(); }
 }
 
-
-// ---- the 4-wave shape ("W4") of the same kernel, for launches that fill the chip ------------------------------------------------------
-// Why: the 8-wave shape above owns a CU (8 waves x ~256 registers, 128 KB of LDS), so nothing overlaps a workgroup's prologue (first-stage
-// HBM round trip, producer, two barriers) and epilogue (exchange through LDS, 32 residual loads and 32 stores per lane at the CU's own
-// vector-memory rate): 28 % of a 128 -> 128 tile with the matrix pipe idle (profiles/r04_wino_trace.txt), and all 256 CUs do it in lock
-// step.  Here a workgroup is 128 co x 4 rows x 32 px held by FOUR waves: wave cf owns channel fragment cf with ALL four transformed
-// components (4 k x 2 position fragments = 128 accumulator registers, as many as a wave of the 8-wave shape), so
-//   * the output transform happens in the wave's own registers -- no partner wave, no exchange buffer, no epilogue barrier;
-//   * a workgroup needs 60 KB of LDS and 4 x 256 registers: TWO independent workgroups per CU, one wave of each on every SIMD, and
-//     one's prologue / epilogue runs beside the other's K loop (what the direct fp16x2 kernel's two co-resident workgroups always did);
-//   * per wave and stage the same 72 MFMAs and (NIT = 2) the same staging share as the 8-wave shape.
-// The price: the 4-row tile's halo (6 staged rows per 4 instead of 10 per 8: +20 % producer / transform / LDS-store work per output) and
-// twice the weight-fragment traffic from L2 per output.  Same K order, same transform order, same GroupNorm sub-tiles: bit-identical to
-// the other two shapes (tests: check_conv_wino).  Which launches take it is decided by the workgroup count like the tile shape
-// (Engine::conv), from same-box measurements (profiles/r05_w4_*.txt).
-template <int ACT, int SC>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino4w_kernel(ConvArgs p) {
-  using G = WinoGeom<4>;
-  using T = WinoTile<4>;
-  using S = SplitH2;
-  constexpr int ROWS = 4, NF = 2, PV = G::PV, NS = 2;
-  constexpr int NIT = (G::NPASS + 3) / 4;             // staging passes per wave (8 passes of 3 staging rows over 4 waves)
-  __shared__ u32x4 s_all[2 * G::STAGE_V + G::CO_V];
-  u32x4* const s_in0 = s_all;
-  u32x4* const s_in1 = s_all + G::STAGE_V;
-  f32x4* const s_co = reinterpret_cast<f32x4*>(s_all + 2 * G::STAGE_V);
-
-  const int tid = threadIdx.x;
-  const int wave = drt_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
-  const int cf = wave;
-  const int Cin = p.C1 + p.C2;
-  const int tiles_xg = (p.W + 31) >> 5;
-  const int tiles_y = (p.H + ROWS - 1) / ROWS;
-  int b, ty, tx;
-  conv_tile_of(p, (int)blockIdx.x, (int)gridDim.x, tiles_xg, tiles_y, b, ty, tx);
-  if (p.rag_w) { if (!conv_ragged_adjust(p, b, tx)) return; }
-  const int H = p.H, W = p.W;
-  const int tiles_x = (W + 31) >> 5;
-  const int co_blk = blockIdx.y;
-  const int x0 = tx * 32, y0 = ty * ROWS;
-  const unsigned HW = (unsigned)H * (unsigned)W;
-
-  // prologue loads, all issued before the first is waited for (as the 8-wave shape; 256 threads carry two coefficient entries each)
-  float xb_raw = 0.f;
-  if (p.xbound) xb_raw = p.xbound[b * kAmaxSpread + (tid & (kAmaxSpread - 1))];
-  float csc[2], csh[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = tid + 256 * h;
-    const bool cld = p.in_scale != nullptr && c < Cin;
-    csc[h] = cld ? p.in_scale[b * Cin + (c < Cin ? c : 0)] : 1.f;
-    csh[h] = cld ? p.in_shift[b * Cin + (c < Cin ? c : 0)] : 0.f;
-  }
-
-  // staging items of this thread (wave pass wave + 4 i): staging row (q, r) = 3 pass + lane / 18, aligned column pair j = lane % 18
-  unsigned it_boff[NIT];
-  int it_woff[NIT], it_q[NIT];
-  bool it_ok[NIT], it_wr[NIT];
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int pass = wave + 4 * i;
-    const int sub = lane / 18, j = lane - 18 * sub;
-    const int rr = 3 * pass + sub;
-    const bool live = sub < 3 && rr < G::NSROW;
-    const int q = rr & 3, r = live ? rr >> 2 : 0;
-    const int gy = y0 - 1 + r, gx = x0 - 2 + 2 * j;
-    const bool ok = live && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    it_boff[i] = ((unsigned)(4 * q) * HW + (ok ? (unsigned)(gy * W + gx) : 0u)) * 4u;
-    it_woff[i] = ((r * 16 + (j - 1)) * PV + (q >> 1) * NS) * 2 + (q & 1);
-    it_q[i] = q; it_ok[i] = ok; it_wr[i] = live && j >= 1 && j <= 16;
-  }
-  float rin[NIT][8];
-  auto load_item = [&](int i, int c0) {
-    const bool first = c0 < p.C1;
-    const float* base = first ? p.src1 + ((size_t)b * p.C1 + c0) * HW : p.src2 + ((size_t)b * p.C2 + (c0 - p.C1)) * HW;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base + (size_t)c * HW) + it_boff[i]);
-      rin[i][2 * c] = v.x; rin[i][2 * c + 1] = v.y;
-    }
-  };
-  float V[4][4];
-  auto produce_co = [&](float x, const f32x4& co, bool ok) -> float {
-    float o = x * co[0] + co[1];
-    if constexpr (ACT == 1) {
-      const float u = x * co[2] + co[3];
-      o = o * __builtin_amdgcn_rcpf(1.0f + drt_exp2(u));
-    }
-    return ok ? o : 0.f;
-  };
-  auto stage_chan_co = [&](int i, int c, const f32x4& co) {
-    const float e = produce_co(rin[i][2 * c], co, it_ok[i]), o = produce_co(rin[i][2 * c + 1], co, it_ok[i]);
-    const float ol = drt_wave_shr1(o), er = drt_wave_shl1(e);
-    V[0][c] = ol - o; V[1][c] = e + o; V[2][c] = o - e; V[3][c] = e - er;
-  };
-  auto flush_item = [&](int i, u32x4* sbuf) {
-    if (it_wr[i]) {
-      uint2* w = reinterpret_cast<uint2*>(sbuf) + it_woff[i];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        uint32_t d01[2], d23[2];
-        S::split2(V[k][0], V[k][1], d01);
-        S::split2(V[k][2], V[k][3], d23);
-        w[k * 8] = make_uint2(d01[0], d23[0]);
-        w[k * 8 + 2] = make_uint2(d01[1], d23[1]);
-      }
-    }
-  };
-
-  const int nst = Cin / G::KC;
-  const float* cs_tab = p.co_scale + (size_t)co_blk * 128;
-  float acc_raw[16];
-  if constexpr (!SC) conv_acc_raw<T>(p, b, co_blk, cf, kg, acc_raw);
-  auto load_cs = [&](float (&cs)[16]) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cs[r] = cs_tab[cf * 32 + 4 * kg + (r & 3) + 8 * (r >> 2)];
-  };
-  float sc_m1 = 0.f, sc_m2 = 0.f;
-  if constexpr (SC) {
-    sc_m1 = p.sc_amax1[b * kAmaxSpread + (tid & (kAmaxSpread - 1))];
-    if (p.sc_amax2) sc_m2 = p.sc_amax2[b * kAmaxSpread + (tid & (kAmaxSpread - 1))];
-  } else {
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) load_item(i, 0);
-  }
-  float kx = 1.f;
-  if (p.xbound) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) xb_raw = fmaxf(xb_raw, __shfl_xor(xb_raw, o));
-    kx = h2_weight_scale(xb_raw);
-  }
-  const float inv_kx = 1.f / kx;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = tid + 256 * h;
-    if (c < Cin) {
-      constexpr float nl2e = -1.4426950408889634f;
-      f32x4 v;
-      v[0] = csc[h] * kx; v[1] = csh[h] * kx; v[2] = csc[h] * nl2e; v[3] = csh[h] * nl2e;
-      s_co[c] = v;
-    }
-  }
-  // accumulators [component k][position fragment]; the additive terms start in M0 and, negated, in M3 (as the 8-wave shape)
-  f32x16 acc[4][NF];
-  {
-    float init0[16], init3[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { init0[r] = 0.f; init3[r] = 0.f; }
-    if constexpr (!SC) {
-      float cs_inv[16];
-      load_cs(cs_inv);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { const float t = acc_raw[r] * (kx / cs_inv[r]); init0[r] = t; init3[r] = -t; }
-    }
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[0][f][r] = init0[r]; acc[1][f][r] = 0.f; acc[2][f][r] = 0.f; acc[3][f][r] = init3[r]; }
-  }
-
-  const u32x4* wblk = reinterpret_cast<const u32x4*>(p.w) + (size_t)co_blk * nst * 12 * NS * 4 * 64;
-  const unsigned a_boff = (unsigned)((cf * 64 + lane) * 16);
-  auto load_a = [&](int st, int tap, u32x4 (&a)[NS]) {        // tap = 4 dy + k
-    const u32x4* q = wblk + (size_t)(st * 12 + tap) * NS * 4 * 64;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s * 4 * 64) + a_boff);
-  };
-  const int b_lane = ((l31 >> 4) * 16 + (l31 & 15)) * PV + kg * NS;
-
-  // one tap = component slot kq of kernel row dy into accumulator set ka: NF position fragments x 3 split products; behind each
-  // fragment's MFMAs one channel of staging item `item` (part 0: channels 0, 1; part 1: channels 2, 3 and the LDS writes)
-  u32x4 bq[2][NS];
-  auto compute_tap = [&](const u32x4* sbuf, int dy, int kq, int ka, const u32x4 (&a)[NS], int item, int part, int c0n, u32x4* nxt) {
-    const u32x4* sb = sbuf + b_lane + dy * G::ROW_V + kq * 4;
-    f32x4 co2[2];
-    if (item >= 0) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) co2[c] = s_co[c0n + 4 * it_q[item] + 2 * part + c];
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) bq[0][s] = sb[s];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      if (f + 1 < NF) {
-        const u32x4* q = sb + (f + 1) * 2 * G::ROW_V;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) bq[(f + 1) & 1][s] = q[s];
-      }
-      __builtin_amdgcn_sched_barrier(SGMSE_SPLIT_FENCE);
-#pragma unroll
-      for (int k = 0; k < S::NP; ++k) acc[ka][f] = S::mfma(a[S::pa(k)], bq[f & 1][S::pb(k)], acc[ka][f]);
-      if (item >= 0) {
-        stage_chan_co(item, 2 * part + f, co2[f]);
-        if (part == 1 && f == NF - 1) flush_item(item, nxt);
-      }
-      __builtin_amdgcn_sched_barrier(SGMSE_SPLIT_FENCE);
-    }
-  };
-
-  if constexpr (SC) {
-    // ---- folded 1x1 shortcut (as the 8-wave shape; here every wave runs both the even columns -> M0 and the negated odd columns -> M3)
-    float m = fmaxf(sc_m1, sc_m2);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    const float xs = h2_weight_scale(m);
-    const int nsts = (p.sc_C1 + p.sc_C2) / G::KC;
-    const int sq = tid & 3, sjm = (tid >> 2) & 15, sr = tid >> 6;      // one item per thread and stage: 4 rows x 16 pairs x 4 channel groups
-    const int sgy = y0 + sr, sgx = x0 + 2 * sjm;
-    const bool s_ok = sgy < H && sgx < W;
-    const unsigned s_boff = ((unsigned)(4 * sq) * HW + (s_ok ? (unsigned)(sgy * W + sgx) : 0u)) * 4u;
-    const int s_woff = (((sr + 1) * 16 + sjm) * PV + (sq >> 1) * NS) * 2 + (sq & 1);
-    const int nss = (nsts + 1) / 2;
-    float rsa[16];
-    auto load_sc = [&](int ss, float (&dst)[16]) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int st = 2 * ss + h < nsts ? 2 * ss + h : nsts - 1;
-        const int c0 = st * G::KC;
-        const bool first = c0 < p.sc_C1;
-        const float* base = first ? p.sc_src1 + ((size_t)b * p.sc_C1 + c0) * HW : p.sc_src2 + ((size_t)b * p.sc_C2 + (c0 - p.sc_C1)) * HW;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base + (size_t)c * HW) + s_boff);
-          dst[8 * h + 2 * c] = v.x; dst[8 * h + 2 * c + 1] = v.y;
-        }
-      }
-    };
-    auto store_sc = [&](const float (&src)[16], u32x4* sbuf, int ss) {
-      uint2* w = reinterpret_cast<uint2*>(sbuf) + s_woff;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (h == 1 && 2 * ss + 1 >= nsts) break;
-        float ev[4], od[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          ev[c] = s_ok ? src[8 * h + 2 * c] * xs : 0.f;
-          od[c] = s_ok ? -(src[8 * h + 2 * c + 1] * xs) : 0.f;
-        }
-        uint32_t d01[2], d23[2];
-        const int ke = h, ko = 3 - h;
-        S::split2(ev[0], ev[1], d01); S::split2(ev[2], ev[3], d23);
-        w[ke * 8] = make_uint2(d01[0], d23[0]); w[ke * 8 + 2] = make_uint2(d01[1], d23[1]);
-        S::split2(od[0], od[1], d01); S::split2(od[2], od[3], d23);
-        w[ko * 8] = make_uint2(d01[0], d23[0]); w[ko * 8 + 2] = make_uint2(d01[1], d23[1]);
-      }
-    };
-    const u32x4* wsc = reinterpret_cast<const u32x4*>(p.sc_w) + (size_t)co_blk * nsts * NS * 4 * 64;
-    auto load_asc = [&](int ss, u32x4 (&a)[2][NS]) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int st = 2 * ss + h < nsts ? 2 * ss + h : nsts - 1;
-        const u32x4* q = wsc + (size_t)st * NS * 4 * 64;
-#pragma unroll
-        for (int s2 = 0; s2 < NS; ++s2) a[h][s2] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(q + s2 * 4 * 64) + a_boff);
-      }
-    };
-    auto compute_sc = [&](const u32x4* sbuf, const u32x4 (&a)[2][NS], int ss) {
-      const bool two = 2 * ss + 1 < nsts;
-      compute_tap(sbuf, 1, 0, 0, a[0], -1, 0, 0, nullptr); if (two) compute_tap(sbuf, 1, 1, 0, a[1], -1, 0, 0, nullptr);
-      compute_tap(sbuf, 1, 3, 3, a[0], -1, 0, 0, nullptr); if (two) compute_tap(sbuf, 1, 2, 3, a[1], -1, 0, 0, nullptr);
-    };
-    u32x4 asc[2][NS];
-    load_sc(0, rsa);
-    load_asc(0, asc);
-    store_sc(rsa, s_in0, 0);
-    if (nss > 1) load_sc(1, rsa);
-    __syncthreads();
-#pragma unroll 1
-    for (int ss = 0; ss < nss; ++ss) {
-      const u32x4* cur = (ss & 1) ? s_in1 : s_in0;
-      u32x4* nxt = (ss & 1) ? s_in0 : s_in1;
-      compute_sc(cur, asc, ss);
-      if (ss + 1 < nss) {
-        load_asc(ss + 1, asc);
-        store_sc(rsa, nxt, ss + 1);
-        if (ss + 2 < nss) load_sc(ss + 2, rsa);
-      }
-      __syncthreads();
-    }
-    float cs_inv[16];
-    load_cs(cs_inv);
-    conv_acc_raw<T>(p, b, co_blk, cf, kg, acc_raw);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float as3 = cs_inv[r] * inv_kx;
-      const int co = co_blk * 128 + cf * 32 + 4 * kg + (r & 3) + 8 * (r >> 2);
-      const float rho = (p.sc_scale[co] / xs) / as3;
-      const float addp = (acc_raw[r] + (p.sc_bias ? p.sc_bias[co < p.Cout ? co : 0] : 0.f)) / as3;
-      const float addn = -1.f * (acc_raw[r] + (p.sc_bias ? p.sc_bias[co < p.Cout ? co : 0] : 0.f)) / as3;
-#pragma unroll
-      for (int f = 0; f < NF; ++f) { acc[0][f][r] = acc[0][f][r] * rho + addp; acc[3][f][r] = acc[3][f][r] * rho + addn; }
-    }
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) load_item(i, 0);
-  }
-  __syncthreads();          // s_co visible (SC: and the last shortcut stage consumed)
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) stage_chan_co(i, c, s_co[4 * it_q[i] + c]);
-    flush_item(i, s_in0);
-    load_item(i, (nst > 1 ? 1 : 0) * G::KC);          // raw inputs one full stage ahead
-  }
-  __syncthreads();
-
-  constexpr int NTAP = 12, AR = 4, AD = AR - 1;
-  u32x4 ar[AR][NS];
-#pragma unroll
-  for (int t = 0; t < AD; ++t) load_a(0, t, ar[t]);
-#pragma unroll 1
-  for (int st = 0; st < nst; ++st) {
-    const int stn = st + 1 < nst ? st + 1 : st;       // the last stage re-stages itself into the buffer nobody reads again
-    const int stl = st + 2 < nst ? st + 2 : nst - 1;
-    const u32x4* cur = (st & 1) ? s_in1 : s_in0;
-    u32x4* nxt = (st & 1) ? s_in0 : s_in1;
-#pragma unroll
-    for (int tap = 0; tap < NTAP; ++tap) {
-      const int ntap = (tap + AD) % NTAP;
-      const int nstg = tap + AD < NTAP ? st : stn;
-      load_a(nstg, ntap, ar[(tap + AD) % AR]);        // issued before the raw loads below: vmcnt retires in order
-      __builtin_amdgcn_sched_barrier(0);
-      // staging of the next stage's items in the first 2 NIT taps (two taps per item); the two waves of a SIMD belong to different
-      // workgroups here and are out of phase by themselves
-      const int item = tap < 2 * NIT ? tap >> 1 : -1, part = tap & 1;
-      compute_tap(cur, tap >> 2, tap & 3, tap & 3, ar[tap % AR], item, part, stn * G::KC, nxt);
-      if (item >= 0 && part == 1) load_item(item, stl * G::KC);
-    }
-    __syncthreads();
-  }
-
-  // ---- output transform in the wave's own registers + epilogue (the 8-wave shape's `finish`, without the exchange) ---------------------
-  int tid_e = (int)threadIdx.x;
-  DRT_PIN_INT(tid_e);
-  const int lane_e = tid_e & 63, l31_e = lane_e & 31, kg_e = lane_e >> 5;
-  const int pos_row = l31_e >> 4, m2 = 2 * (l31_e & 15);
-  const int yb = y0 + pos_row, x = x0 + m2;
-  const bool okc = x < W;
-  const bool inside = x0 + 32 <= W && y0 + ROWS <= H;
-  const size_t ubase = (size_t)b * p.Cout * HW;
-  const int co_l = co_blk * 128 + cf * 32 + 4 * kg_e;
-  unsigned lane_boff[NF];
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    const int yy = yb + 2 * f < H ? yb + 2 * f : H - 1;
-    lane_boff[f] = (((unsigned)co_l * (unsigned)H + (unsigned)yy) * (unsigned)W + (unsigned)(okc ? x : 0)) * 4u;
-  }
-  auto soff = [&](int r) -> unsigned { return (unsigned)((r & 3) + 8 * (r >> 2)) * HW * 4u; };
-  const drt_buf obuf = drt_make_buf(p.out + ubase), rbuf = drt_make_buf(p.res ? p.res + ubase : p.out);
-  const bool has_res = !SC && p.res != nullptr;
-  float2 rr[SC ? 1 : NF][SC ? 1 : 16];
-  if constexpr (!SC) {
-    if (has_res) {
-#pragma unroll
-      for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rr[f][r] = drt_buf_load2(rbuf, lane_boff[f], soff(r));
-    }
-  }
-  // y(2m) = (M0 + M1) + M2, y(2m+1) = M1 - (M2 + M3), in exactly the order the partner waves of the 8-wave shape form them
-#pragma unroll
-  for (int f = 0; f < NF; ++f)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float a1 = acc[1][f][r], a0 = acc[0][f][r] + a1;
-      const float b0 = acc[2][f][r], b1 = b0 + acc[3][f][r];
-      acc[0][f][r] = a0 + b0; acc[1][f][r] = a1 - b1;
-    }
-  auto finish = [&](auto guard_tag) {
-    constexpr bool GUARD = decltype(guard_tag)::value;
-    float cs_inv[16];
-    load_cs(cs_inv);
-    float s1[16], s2[16], vmax = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      const bool ok = !GUARD || (okc && yb + 2 * f < H);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v0 = acc[0][f][r] * cs_inv[r] * inv_kx, v1 = acc[1][f][r] * cs_inv[r] * inv_kx;      // exact powers of two
-        if constexpr (!SC) { if (has_res) { v0 += rr[f][r].x; v1 += rr[f][r].y; } }
-        v0 *= p.out_scale; v1 *= p.out_scale;
-        if (ok) drt_buf_store2(obuf, make_float2(v0, v1), lane_boff[f], soff(r));
-        if (GUARD) { v0 = ok ? v0 : 0.f; v1 = ok ? v1 : 0.f; }
-        vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
-        s1[r] = (s1[r] + v0) + v1;
-        s2[r] = (s2[r] + v0 * v0) + v1 * v1;
-      }
-      DRT_PIN_HERE(vmax);
-    }
-    if (p.stats_out && y0 < H) {
-      auto butterfly = [&](float (&sv)[16]) -> float {
-        float a[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] = drt_xadd<16>(sv[k], sv[k + 8]);
-        float c[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) c[k] = drt_xadd<8>(a[k], a[k + 4]);
-        const float d0 = drt_xadd<7>(c[0], c[2]), d1 = drt_xadd<7>(c[1], c[3]);
-        return drt_add_xor2(drt_xadd<1>(d0, d1));
-      };
-      const float e2 = butterfly(s2);
-      __builtin_amdgcn_sched_barrier(0);
-      const float e1 = butterfly(s1);
-      const int r = ((l31_e >> 4) & 1) * 8 + ((l31_e >> 3) & 1) * 4 + ((l31_e >> 2) & 1) * 2 + (l31_e & 1);
-      const int co = co_l + (r & 3) + 8 * (r >> 2);
-      float* so = p.stats_out + ((size_t)(b * p.Cout + co) * p.stats_nsub + (size_t)(y0 >> 2) * tiles_x + tx) * 2;
-      so[0] = e1; so[1] = e2;
-    }
-    if (p.amax_out) {
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-      if (lane_e == 0) drt_atomic_max_nonneg(p.amax_out + b * kAmaxSpread + ((blockIdx.x * 4 + wave) & (kAmaxSpread - 1)), vmax);
-    }
-    DRT_CODE_MARKER(GUARD);
-  };
-  if (inside) finish(std::false_type{}); else finish(std::true_type{});
-}
-
 }  // namespace sgmse

@@ -107,10 +107,8 @@ def check_conv_wino(dev, B, Ci, Co, H, W, dual=0, xform=True, res=True, xmul=1.0
     kw = dict(residual=mv(r), out_scale=1 / math.sqrt(2.0), x2=mv(x2), in_scale=mv(sc), in_shift=mv(sh), in_act=xform)
     out8 = ops.conv2d(mv(x1), mv(w), mv(b), force_split="wino", **kw).cpu()
     out4 = ops.conv2d(mv(x1), mv(w), mv(b), force_split="wino4", **kw).cpu()
-    out4w = ops.conv2d(mv(x1), mv(w), mv(b), force_split="wino4w", **kw).cpu()
     out_f32 = ops.conv2d(mv(x1), mv(w), mv(b), **kw).cpu()
     assert torch.equal(out8, out4), "the 4-row and 8-row Winograd shapes differ"
-    assert torch.equal(out8, out4w), "the 4-wave and 8-row Winograd shapes differ"
     # per-channel error: an outlier channel must not cost the others their accuracy
     if wmul:
         num = (out8.double() - ref64).pow(2).sum(dim=(0, 2, 3)).sqrt(); den = ref64.pow(2).sum(dim=(0, 2, 3)).sqrt()
@@ -311,16 +309,13 @@ def check_split_workgroup_shapes_bitwise(dev, name="fwd_nf128"):
     cfg = NET_CASES[name]
     z = load(name)
     x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
-    keys = ("SGMSE_SPLIT_MIN_TILES", "SGMSE_TILE_MIN_BLOCKS", "SGMSE_WINO_W4")
+    keys = ("SGMSE_SPLIT_MIN_TILES", "SGMSE_TILE_MIN_BLOCKS")
     old = {k: os.environ.get(k) for k in keys}
     outs = []
     try:
         os.environ["SGMSE_SPLIT_MIN_TILES"] = "1"
-        # 8-row shapes everywhere, 4-row shapes everywhere, and the Winograd kernel's 4-wave shape on every launch it is eligible for
-        # (incl. the folded-shortcut instantiation, which the op-level test does not reach)
-        for m, w4 in (("1", "0"), ("1000000000", "0"), ("1", "1")):
+        for m in ("1", "1000000000"):
             os.environ["SGMSE_TILE_MIN_BLOCKS"] = m
-            os.environ["SGMSE_WINO_W4"] = w4
             net, _ = make_backbone(cfg, dev)
             outs.append(net(x.to(dev), t.to(dev)).cpu())
     finally:
@@ -330,7 +325,6 @@ def check_split_workgroup_shapes_bitwise(dev, name="fwd_nf128"):
             else:
                 os.environ[k] = v
     assert torch.equal(outs[0], outs[1])
-    assert torch.equal(outs[0], outs[2]), "the Winograd kernel's 4-wave shape changes the network's output"
     assert rel_l2(outs[0], torch.from_numpy(z["out"])) < NET_TOL
 
 
