@@ -170,9 +170,9 @@ import sys, json
 d = json.loads(sys.stdin.read()); print('   ', round(d['value'], 4), d['unit'], round(d['ms_per_step'], 1), 'ms/step')"; }
   for L in $LIB_A $LIB_B $LIB_B $LIB_A; do
     echo "== lib: $L" | tee -a $O/${TAG}_libab.txt
-    SGMSE_LIB_PATH=$PWD/$L VARIANTS=${VARIANTS:-1152} SHAPES=${SHAPES:-0,1,2} FUSED=1 ROUNDS=3 timeout 200 python tools/conv_microbench.py 2>&1 | grep "ms " | tee -a $O/${TAG}_libab.txt
+    [ -z "$LIBAB_SKIP_MICRO" ] && SGMSE_LIB_PATH=$PWD/$L VARIANTS=${VARIANTS:-1152} SHAPES=${SHAPES:-0,1,2} FUSED=1 ROUNDS=3 timeout 200 python tools/conv_microbench.py 2>&1 | grep "ms " | tee -a $O/${TAG}_libab.txt
     runbench $L "--steps 2 --warmup 1 --no-others --no-cpu-baseline --no-profile" | tee -a $O/${TAG}_libab.txt
-    runbench $L "--batch 1 --steps 3 --warmup 1 --no-others --no-cpu-baseline --no-profile" | tee -a $O/${TAG}_libab.txt
+    [ -z "$LIBAB_SKIP_B1" ] && runbench $L "--batch 1 --steps 3 --warmup 1 --no-others --no-cpu-baseline --no-profile" | tee -a $O/${TAG}_libab.txt
   done
 fi
 echo "== done"
