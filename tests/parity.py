@@ -452,14 +452,16 @@ def replay_noise(shape, ndraws, seed=7):
     return torch.stack([rep(like) for _ in range(ndraws)])
 
 
-def check_ode_rk45(dev, full=True):
+def check_ode_rk45(dev, full=True, name="ode_rk45"):
     """The reference's adaptive probability-flow sampler (get_ode_sampler with denoise=False: scipy RK45 over the flattened state,
-    sampling/__init__.py:96-143) against the reference's own run (tests/golden/ode_rk45.npz, oracle/make_golden_ode.py).
-    The trajectory of the random-weight network is sensitive (the oracle's own end state is 3.7e-4 from the reference's), so the parity
-    gate sits where the product computes: the drift handed to the solver, at the reference's own evaluation points (1e-5); the end
-    state is bounded at 2e-2 and the solver's evaluation count must stay within two steps of the reference's."""
+    sampling/__init__.py:96-143) against the reference's own run (oracle/make_golden_ode.py).  Two fixtures: ``ode_rk45`` at
+    rtol = atol = 1e-3 (92 evaluations) and ``ode_rk45_default`` at the reference's default 1e-5 (722 evaluations).
+    Gates: (1) the drift handed to the solver at the reference's own evaluation points, 1e-5 -- where the product computes; (2) the
+    solver's evaluation count within two steps of the reference's; (3) the end state: at the default tolerance the integration is
+    well conditioned (the oracle's own end state is 1.8e-5 from the reference's) and the gate is the samplers' 1e-4; at 1e-3 the step
+    control amplifies last-digit differences of the network (oracle: 3.7e-4), so the bound is 5x the oracle's own deviation."""
     from sgmse_amd import sampling
-    z = load("ode_rk45")
+    z = load(name)
     cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
     m, _ = make_model(cfg, dev)
     y = torch.from_numpy(z["y"]).to(dev)
@@ -471,7 +473,7 @@ def check_ode_rk45(dev, full=True):
             xt = torch.from_numpy(xk.reshape(tuple(y.shape))).to(dev)
             f = rsde.sde(xt, y, torch.ones(y.shape[0], device=dev) * float(t))[0]
             worst = max(worst, rel_l2(f.cpu().reshape(-1), torch.from_numpy(fk)))
-    print(f"ode_rk45 on {dev}: drift at {len(z['probe_t'])} of the reference's evaluation points, worst rel_l2 = {worst:.3e}")
+    print(f"{name} on {dev}: drift at {len(z['probe_t'])} of the reference's evaluation points, worst rel_l2 = {worst:.3e}")
     assert worst < 1e-5, worst
     if not full:
         return
@@ -479,9 +481,11 @@ def check_ode_rk45(dev, full=True):
     sampler = m.get_ode_sampler(y, denoise=False, rtol=float(z["rtol"]), atol=float(z["atol"]), method="RK45", noise=noise)
     out, nfe = sampler()
     err = rel_l2(out.cpu(), torch.from_numpy(z["out"]))
-    print(f"ode_rk45 on {dev}: solver evaluations {nfe} (reference {int(z['nfe'])}), end state rel_l2 vs the reference's = {err:.3e} "
-          f"(the oracle's own: {float(z['oracle_vs_reference']):.3e})")
-    assert abs(nfe - int(z["nfe"])) <= 12 and err < 2e-2, (nfe, err)
+    own = float(z["oracle_vs_reference"])
+    bound = SAMPLER_TOL if float(z["rtol"]) <= 1e-5 else 5.0 * own
+    print(f"{name} on {dev}: solver evaluations {nfe} (reference {int(z['nfe'])}), end state rel_l2 vs the reference's = {err:.3e} "
+          f"(the oracle's own: {own:.3e}; bound {bound:.1e})")
+    assert abs(nfe - int(z["nfe"])) <= 12 and err < bound, (nfe, err, bound)
 
 
 def check_sampler_golden(dev, tag, batch=None, use_graph=True):
@@ -701,10 +705,17 @@ def check_sb_golden(dev, stype, batch=None, use_graph=True):
             w_y = at / (aT * sT ** 2 + sde.eps) * (st ** 2 - sp * st * sbt / (sbp + sde.eps))
             xt = b4(w_prev) * xt + b4(w_est) * est_hip + b4(w_y) * y
             sp, sbp, ap = st, sbt, at
+    # State bound from the conditioning model of tools/sb_conditioning.py (profiles/r03_sb_conditioning.txt): a relative difference delta of
+    # the network estimates moves the sample by sqrt(delta * 0.446 * 4.5e-4) (the first step's quantum ulp(w_prev |y|) / |y| = 4.57e-4 turns a
+    # perturbation into a random walk over that grid); measured on MI355X 7.2e-5 at delta = 5.1e-6, 2.3x the model.  Bound: 4x the model at
+    # the delta measured in THIS run (round 4: a flat 1e-3) -- a 10x slip of the fused loop's own weight arithmetic no longer passes.
+    pred = math.sqrt(max(worst, 1e-7) * 0.446 * 4.5e-4)
+    mutual = rel_l2(xt, out.cpu())
     print(f"sb_ode_N4 on {dev}: worst per-step network estimate vs the oracle at the same input = {worst:.3e} (gate {OP_TOL:.0e}); "
-          f"state vs the reference's output: fused loop {err:.3e}, reference-style loop {rel_l2(xt, ref):.3e} (information; bound 1e-3)")
+          f"state vs the reference's output: fused loop {err:.3e}, reference-style loop {rel_l2(xt, ref):.3e}, fused vs reference-style loop "
+          f"{mutual:.3e} (conditioning model at this delta: {pred:.1e}; bounds 4x / 8x)")
     assert worst < OP_TOL, worst
-    assert err < 1e-3 and rel_l2(xt, out.cpu()) < 1e-3
+    assert err < 4.0 * pred and mutual < 8.0 * pred, (err, mutual, pred)
 
 
 def check_weight_reload(dev):

@@ -487,9 +487,12 @@ def test_maximum_batch_more_than_2_to_the_31_activation_elements(hip):
     net(x3, t3)                                  # back to a small shape: the arena is re-planned (and stays allocated)
 
 
-def test_adaptive_ode_sampler_matches_the_reference_run(hip):
-    """get_ode_sampler(denoise=False): the reference's scipy RK45 path, every function evaluation one network evaluation on the GPU."""
-    P.check_ode_rk45(hip)
+@pytest.mark.parametrize("name", ["ode_rk45", "ode_rk45_default"])
+def test_adaptive_ode_sampler_matches_the_reference_run(hip, name):
+    """get_ode_sampler(denoise=False): the reference's scipy RK45 path, every function evaluation one network evaluation on the GPU;
+    at rtol = atol = 1e-3 (drift gate 1e-5, end state within 5x the oracle's own deviation) and at the reference's default 1e-5
+    (722 evaluations, end state within the samplers' 1e-4)."""
+    P.check_ode_rk45(hip, name=name)
 
 
 def test_profile_of_one_evaluation_times_the_ordinary_forward(hip):
@@ -606,3 +609,40 @@ print('RCCL-OK params %%d (%%.0f MB) broadcast %%.1f ms' %% (n, n * 4 / 1e6, ms)
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     print(out.stdout[-400:])
     assert "RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_two_processes_on_the_one_gpu_only_pay_for_sharing_the_device(hip):
+    """8-GPU rehearsal on the hardware there is.  The scaling run is eight INDEPENDENT processes on one host, each
+    launching its own captured graph: anything they would serialise on the host (pinned staging, a graph-launch lock, the rocm-smi
+    sampler, the weight loader) would show there for the first time.  Two bench.py processes on the ONE visible GPU, concurrently, each a
+    batch-8 step: together they must deliver about what one process alone delivers -- the device is time-shared, so each takes ~2x as
+    long; the gate (2.6x) leaves room for the sharing itself and fails on host-side serialisation beyond it.  The slowdown is printed."""
+    import json
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--steps", "3", "--warmup", "1", "--no-others", "--no-cpu-baseline",
+           "--no-profile"]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "0"))
+
+    def line(p):
+        out, err = p.communicate(timeout=900)
+        rows = [l for l in out.splitlines() if l.startswith("{")]
+        assert p.returncode == 0 and len(rows) == 1, out[-2000:] + err[-2000:]
+        return json.loads(rows[0])
+
+    solo = line(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT) for _ in range(2)]
+    both = [line(p) for p in procs]
+    wall = time.perf_counter() - t0
+    ratio = max(b["ms_per_step"] for b in both) / solo["ms_per_step"]
+    together = sum(b["value"] for b in both)
+    print(f"two processes on one GPU: solo {solo['ms_per_step']:.0f} ms/step ({solo['value']:.2f} utt/s); concurrently "
+          f"{both[0]['ms_per_step']:.0f} / {both[1]['ms_per_step']:.0f} ms/step, {together:.2f} utt/s together, slowdown {ratio:.2f}x "
+          f"(wall {wall:.0f} s incl. start-up)")
+    assert all(b["graph_captures_rank0"] == 1 for b in both)
+    # (the two timed regions overlap only partly -- start-up skew -- so the slower one sees between 1x and ~2x)
+    assert ratio < 2.6, ratio
+    assert together > 0.75 * solo["value"], (together, solo["value"])

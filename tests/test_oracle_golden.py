@@ -136,11 +136,13 @@ def test_sb_sampler_matches_reference(stype):
     assert n == 4 and rel_l2(out, z["out"]) < 1e-4
 
 
-def test_adaptive_ode_oracle_reproduces_the_reference_drift_and_run():
-    """oracle/sde_oracle.py::ode_sample_adaptive against the reference's get_ode_sampler(denoise=False) run (tests/golden/ode_rk45.npz,
-    oracle/make_golden_ode.py): the drift at the reference's own evaluation points always; the whole trajectory under SGMSE_SLOW=1."""
+@pytest.mark.parametrize("name", ["ode_rk45", "ode_rk45_default"])
+def test_adaptive_ode_oracle_reproduces_the_reference_drift_and_run(name):
+    """oracle/sde_oracle.py::ode_sample_adaptive against the reference's get_ode_sampler(denoise=False) runs (tests/golden/ode_rk45.npz at
+    rtol = atol = 1e-3, ode_rk45_default.npz at the reference's default 1e-5; oracle/make_golden_ode.py): the drift at the reference's
+    own evaluation points always; the whole trajectory under SGMSE_SLOW=1."""
     import os
-    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ode_rk45.npz"))
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
     P = synth.synth_params(cfg, seed=0)
     y = torch.from_numpy(z["y"])
@@ -156,4 +158,4 @@ def test_adaptive_ode_oracle_reproduces_the_reference_drift_and_run():
         out, nfe = SO.ode_sample_adaptive(so, lambda a, b, c: NO.score_fn(P, cfg, a, b, c), y, SO.NoiseReplay(7), eps=float(z["eps"]),
                                           rtol=float(z["rtol"]), atol=float(z["atol"]))
         err = float((out - torch.from_numpy(z["out"])).norm() / torch.from_numpy(z["out"]).norm())
-        assert nfe == int(z["nfe"]) and err < 2e-2, (nfe, err)
+        assert nfe == int(z["nfe"]) and err < 1.05 * float(z["oracle_vs_reference"]) + 1e-7, (nfe, err)     # (what the fixture script measured)
