@@ -123,6 +123,12 @@ int sgmse_spec_back(sgmse_ctx* ctx, const void* in, void* out, long long n, int 
  *    out fp32 [BC][(H*up_y+pad_y0+pad_y1-kh)/down_y+1][(W*up_x+pad_x0+pad_x1-kw)/down_x+1]. */
 int sgmse_upfirdn2d(sgmse_ctx* ctx, const float* input, const float* kernel, float* out, int BC, int H, int W, int kh,
                     int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1);
+/*    The same op over the other element types the reference dispatches (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ *    op/upfirdn2d_kernel.cu:311): dtype 0 = float (as above), 1 = double, 2 = half (IEEE binary16 bits; fp32 accumulation, one
+ *    rounding on the way out).  input, kernel and out share the element type. */
+int sgmse_upfirdn2d_dtype(sgmse_ctx* ctx, int dtype, const void* input, const void* kernel, void* out, int BC, int H, int W,
+                          int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                          int pad_y1);
 
 /* -- single layers, exported for per-op parity tests (all NCHW fp32) --------------------------------------------
  * conv2d: F.conv2d(cat[x, x2], w, bias, padding=ks/2) (layers.py:100-124), optionally with a fused per-(b,c)

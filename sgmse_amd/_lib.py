@@ -61,6 +61,7 @@ _SIGS = {
     "sgmse_spec_fwd": (_I, [_P, _P, _P, _LL, _I, _F, _F]),
     "sgmse_spec_back": (_I, [_P, _P, _P, _LL, _I, _F, _F]),
     "sgmse_upfirdn2d": (_I, [_P, _P, _P, _P] + [_I] * 13),
+    "sgmse_upfirdn2d_dtype": (_I, [_P, _I, _P, _P, _P] + [_I] * 13),
     "sgmse_op_conv2d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _P, _I]),
     "sgmse_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I]),
     "sgmse_conv_split_mode": (_I, [_P, _P]),

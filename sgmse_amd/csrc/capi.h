@@ -147,7 +147,15 @@ int sgmse_upfirdn2d(sgmse_ctx* ctx, const float* input, const float* kernel, flo
                     int up_x, int up_y, int down_x, int down_y, int px0, int px1, int py0, int py1) {
   SG_ARG(ctx, input && kernel && out && BC > 0 && H > 0 && W > 0 && kh > 0 && kw > 0, "null pointer or non-positive shape");
   SG_ARG(ctx, up_x >= 1 && up_y >= 1 && down_x >= 1 && down_y >= 1, "up/down factors must be >= 1");
-  return sg_guard(ctx, [&](sgmse::Engine& e) { e.op_upfirdn2d(input, kernel, out, BC, H, W, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1); });
+  return sg_guard(ctx, [&](sgmse::Engine& e) { e.op_upfirdn2d(0, input, kernel, out, BC, H, W, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1); });
+}
+
+int sgmse_upfirdn2d_dtype(sgmse_ctx* ctx, int dtype, const void* input, const void* kernel, void* out, int BC, int H, int W, int kh, int kw,
+                          int up_x, int up_y, int down_x, int down_y, int px0, int px1, int py0, int py1) {
+  SG_ARG(ctx, dtype >= 0 && dtype <= 2, "dtype must be 0 (float), 1 (double) or 2 (half)");
+  SG_ARG(ctx, input && kernel && out && BC > 0 && H > 0 && W > 0 && kh > 0 && kw > 0, "null pointer or non-positive shape");
+  SG_ARG(ctx, up_x >= 1 && up_y >= 1 && down_x >= 1 && down_y >= 1, "up/down factors must be >= 1");
+  return sg_guard(ctx, [&](sgmse::Engine& e) { e.op_upfirdn2d(dtype, input, kernel, out, BC, H, W, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1); });
 }
 
 int sgmse_op_conv2d(sgmse_ctx* ctx, const float* x, const float* w, const float* bias, const float* res, float* out, int B, int Cin,

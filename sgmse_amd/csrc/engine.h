@@ -630,13 +630,17 @@ class Engine {
     check_launch();
   }
 
-  void op_upfirdn2d(const float* x, const float* kern, float* out, int BC, int H, int W, int kh, int kw, int up_x, int up_y,
+  // dtype: 0 float, 1 double, 2 half (the element types of the reference op, op/upfirdn2d_kernel.cu:311)
+  void op_upfirdn2d(int dtype, const void* x, const void* kern, void* out, int BC, int H, int W, int kh, int kw, int up_x, int up_y,
                     int down_x, int down_y, int px0, int px1, int py0, int py1) {
     UpfirdnArgs a{x, kern, out, BC, H, W, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1, 0, 0};
     a.Ho = (H * up_y + py0 + py1 - kh) / down_y + 1;
     a.Wo = (W * up_x + px0 + px1 - kw) / down_x + 1;
     SG_REQUIRE(a.Ho > 0 && a.Wo > 0, "upfirdn2d: empty output");
-    DRT_LAUNCH(upfirdn2d_generic_kernel, dim3((a.Ho * a.Wo + 255) / 256, BC), dim3(256), stream_, a);
+    const dim3 grid((a.Ho * a.Wo + 255) / 256, BC);
+    if (dtype == 0) DRT_LAUNCH(upfirdn2d_generic_kernel<UpfirdnF32>, grid, dim3(256), stream_, a);
+    else if (dtype == 1) DRT_LAUNCH(upfirdn2d_generic_kernel<UpfirdnF64>, grid, dim3(256), stream_, a);
+    else DRT_LAUNCH(upfirdn2d_generic_kernel<UpfirdnF16>, grid, dim3(256), stream_, a);
     check_launch();
   }
 

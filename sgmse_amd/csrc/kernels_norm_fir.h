@@ -375,17 +375,32 @@ inline bool fir_use_tiled(int W) { return W % 4 == 0 && W >= 64; }
 // Generic upfirdn2d (reference op/upfirdn2d.py:162-203 semantics): zero-insert by `up`, pad/crop, correlate with the
 // flipped kernel, decimate by `down`.  grid = (ceil(Ho*Wo/256), BC).
 struct UpfirdnArgs {
-  const float* src; const float* kern; float* out;
+  const void* src; const void* kern; void* out;
   int BC, H, W, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, Ho, Wo;
 };
+// element types the reference op dispatches (AT_DISPATCH_FLOATING_TYPES_AND_HALF, op/upfirdn2d_kernel.cu:311): float, double, half.
+// Half is stored as its 16 bits, read into fp32, accumulated in fp32 and rounded once on the way out (the reference's CUDA kernel
+// accumulates in scalar_t, i.e. rounds the running sum to half after every tap: this result is the closer one to the exact sum).
+struct UpfirdnF32 { using elem = float; using acc = float;
+  static __device__ __forceinline__ acc load(const elem* p, size_t i) { return p[i]; }
+  static __device__ __forceinline__ void store(elem* p, size_t i, acc v) { p[i] = v; } };
+struct UpfirdnF64 { using elem = double; using acc = double;
+  static __device__ __forceinline__ acc load(const elem* p, size_t i) { return p[i]; }
+  static __device__ __forceinline__ void store(elem* p, size_t i, acc v) { p[i] = v; } };
+struct UpfirdnF16 { using elem = uint16_t; using acc = float;
+  static __device__ __forceinline__ acc load(const elem* p, size_t i) { return drt_f16_to_f32(p[i]); }
+  static __device__ __forceinline__ void store(elem* p, size_t i, acc v) { p[i] = (uint16_t)drt_f32_to_f16(v); } };
 
+template <class E>
 __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnArgs p) {
+  using T = typename E::elem;
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= p.Ho * p.Wo) return;
   const int bc = blockIdx.y;
   const int oy = o / p.Wo, ox = o - oy * p.Wo;
-  const float* plane = p.src + (size_t)bc * p.H * p.W;
-  float acc = 0.f;
+  const T* plane = static_cast<const T*>(p.src) + (size_t)bc * p.H * p.W;
+  const T* kern = static_cast<const T*>(p.kern);
+  typename E::acc acc = 0;
   for (int a = 0; a < p.kh; ++a) {
     // position in the zero-inserted, padded signal
     const int zy = oy * p.down_y + a - p.pad_y0;
@@ -397,10 +412,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnArgs p) {
       if (zx < 0 || zx % p.up_x != 0) continue;
       const int ix = zx / p.up_x;
       if (ix >= p.W) continue;
-      acc += p.kern[(p.kh - 1 - a) * p.kw + (p.kw - 1 - c)] * plane[iy * p.W + ix];
+      acc += E::load(kern, (size_t)(p.kh - 1 - a) * p.kw + (p.kw - 1 - c)) * E::load(plane, (size_t)iy * p.W + ix);
     }
   }
-  p.out[(size_t)bc * p.Ho * p.Wo + o] = acc;
+  E::store(static_cast<T*>(p.out), (size_t)bc * p.Ho * p.Wo + o, acc);
 }
 
 }  // namespace sgmse

@@ -93,17 +93,22 @@ def fir_resample(x: torch.Tensor, up: bool, in_scale: Optional[torch.Tensor] = N
 
 def upfirdn2d(x: torch.Tensor, kernel: torch.Tensor, up: int = 1, down: int = 1, pad: Tuple[int, int] = (0, 0)) -> torch.Tensor:
     """upfirdn2d(input[N,C,H,W], kernel[kh,kw], up, down, pad) with the same pad on both axes
-    (reference op/upfirdn2d.py:148-159)."""
+    (reference op/upfirdn2d.py:148-159).  float32, float64 and float16 inputs run in their own element type like the reference op
+    (op/upfirdn2d_kernel.cu:311; half accumulates in fp32); the kernel is cast to the input's type; other dtypes go through float32."""
     ctx = default_context(x.device)
-    x = _f32(x, "input", ctx.device); kernel = _f32(kernel, "kernel", ctx.device)
+    code = {torch.float32: 0, torch.float64: 1, torch.float16: 2}.get(x.dtype)
+    if code is None:
+        x, code = x.float(), 0
+    dt = x.dtype
+    x = _lib.check_tensor(x, "input", dt, ctx.device); kernel = kernel.to(device=ctx.device, dtype=dt).contiguous()
     N, Cc, H, W = x.shape
     kh, kw = kernel.shape
     Ho = (H * up + pad[0] + pad[1] - kh) // down + 1
     Wo = (W * up + pad[0] + pad[1] - kw) // down + 1
-    out = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=ctx.device)
+    out = torch.empty((N, Cc, Ho, Wo), dtype=dt, device=ctx.device)
     ctx.use_current_stream()
-    ctx.check(ctx.lib.sgmse_upfirdn2d(ctx.h, x.data_ptr(), kernel.data_ptr(), out.data_ptr(), N * Cc, H, W, kh, kw, up, up,
-                                      down, down, pad[0], pad[1], pad[0], pad[1]))
+    ctx.check(ctx.lib.sgmse_upfirdn2d_dtype(ctx.h, code, x.data_ptr(), kernel.data_ptr(), out.data_ptr(), N * Cc, H, W, kh, kw, up, up,
+                                            down, down, pad[0], pad[1], pad[0], pad[1]))
     return out
 
 

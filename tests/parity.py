@@ -188,6 +188,19 @@ def check_fir_golden(dev):
     k4 = (k4 / k4.sum()).to(dev)
     assert rel_l2(ops.upfirdn2d(x, k4, down=2, pad=(1, 1)).cpu(), z["down"]) < 1e-6
     assert rel_l2(ops.upfirdn2d(x, k4 * 4, up=2, pad=(2, 1)).cpu(), z["up"]) < 1e-6
+    # the other element types the reference op dispatches (op/upfirdn2d_kernel.cu:311): double against the same fixtures in its own
+    # precision, half within half's rounding of the fp32 result (fp32 accumulation, one rounding)
+    for args, key in ((dict(up=3, down=2, pad=(2, 1)), "generic"), (dict(down=2, pad=(1, 1)), "down")):
+        kk = k if key == "generic" else k4
+        o64 = ops.upfirdn2d(x.double(), kk.double(), **args)
+        assert o64.dtype == torch.float64 and rel_l2(o64.cpu(), torch.from_numpy(z[key]).double()) < 1e-6
+        ref64 = F.conv2d(F.pad(x.cpu().double(), (1, 1, 1, 1)).reshape(-1, 1, x.shape[2] + 2, x.shape[3] + 2),
+                         torch.flip(k4.cpu().double(), [0, 1])[None, None], stride=2) if key == "down" else None
+        if ref64 is not None:          # double really computes in double: 1e-12 against an fp64 convolution of the same op
+            assert rel_l2(o64.cpu().reshape(ref64.shape), ref64) < 1e-12
+        o16 = ops.upfirdn2d(x.half(), kk.half(), **args)
+        o32 = ops.upfirdn2d(x.half().float(), kk.half().float(), **args)
+        assert o16.dtype == torch.float16 and torch.equal(o16.cpu(), o32.half().cpu())      # = the fp32 result of the same half inputs, rounded once
 
 
 def check_attention(dev, B, C, S):
