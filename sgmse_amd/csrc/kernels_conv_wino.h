@@ -41,6 +41,10 @@
 #pragma once
 #include "kernels_conv_split.h"
 
+#ifndef SGMSE_WINO_TAIL_STAGING
+#define SGMSE_WINO_TAIL_STAGING 0
+#endif
+
 namespace sgmse {
 
 template <int ROWS_>
@@ -498,9 +502,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(ConvArgs p) {
       constexpr int BT0 = NTAP - NIT;
       const bool ca = tap < NIT, cb = tap >= BT0 && tap < BT0 + NIT;   // (constants once the tap loop is unrolled)
       const int item = ca ? tap : cb ? tap - BT0 : -1;
-      const bool stage_here = !(ABL & 8) && item >= 0 && it_run[item < 0 ? 0 : item] && (ca ? kh == 0 : kh == 1);
+      // Round 5: the LAST stage has nothing to stage and the last TWO have nothing to load -- until then the last stage re-staged itself
+      // into the buffer nobody reads again (producer, transform, split and LDS stores of a full tile) and both reloaded the last stage's
+      // raw inputs: 1/8 of a 128-channel layer's staging work and 1/4 of its raw loads, dead (SGMSE_WINO_TAIL_STAGING=1 restores it for the A/B)
+      const bool stage_live = SGMSE_WINO_TAIL_STAGING || st + 1 < nst, load_live = SGMSE_WINO_TAIL_STAGING || st + 2 < nst;
+      const bool stage_here = !(ABL & 8) && item >= 0 && it_run[item < 0 ? 0 : item] && (ca ? kh == 0 : kh == 1) && stage_live;
       compute_tap(cur, tap, 2 * kh + (tap & 1), ar[tap % AR], item, stage_here, stn * G::KC, nxt);
-      if constexpr (!(ABL & 16)) { if (stage_here) load_item(item < 0 ? 0 : item, stl * G::KC); }
+      if constexpr (!(ABL & 16)) { if (stage_here && load_live) load_item(item < 0 ? 0 : item, stl * G::KC); }
       if constexpr (TRACE) { __builtin_amdgcn_sched_barrier(0); ttap[tap] += drt_clock() - tc0; }
     }
     if constexpr (TRACE) {
