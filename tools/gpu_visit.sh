@@ -120,13 +120,13 @@ if has pmcbench; then
   if [ -n "$PMCB_GRAPH_PROBE" ]; then      # does counter collection survive the REPLAYED GRAPH? one pass, recorded next to the eager ones
     timeout ${PMCB_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "${PMCB_REGEX:-conv3x3_wino_kernel}" --output-format csv -d $O/pmcb/graph_probe -o pmc -- \
       python bench.py --batch $PB --steps 1 --warmup 0 --N 2 --no-others --no-cpu-baseline --no-profile > $O/pmcb/graph_probe.log 2>&1
-    echo "pmcbench graph probe rc=$?; rows: $(cat $O/pmcb/graph_probe/*/*counter_collection.csv 2>/dev/null | wc -l); bench line: $(grep -o '"value": [0-9.]*' $O/pmcb/graph_probe.log | head -1)" | tee $O/${TAG}_pmc_bench_graph_probe.txt
+    echo "pmcbench graph probe rc=$?; rows: $(find $O/pmcb/graph_probe -name "*counter_collection.csv" -exec cat {} + 2>/dev/null | wc -l); bench line: $(grep -o '"value": [0-9.]*' $O/pmcb/graph_probe.log | head -1)" | tee $O/${TAG}_pmc_bench_graph_probe.txt
   fi
   for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
     n=$(echo $grp | cut -d' ' -f1)
     timeout ${PMCB_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "${PMCB_REGEX:-conv3x3_wino_kernel}" --output-format csv -d $O/pmcb/$n -o pmc -- \
       python bench.py --batch $PB $PMCB_BASE --no-others --no-cpu-baseline --no-profile $PMCB_ARGS > $O/pmcb/$n.log 2>&1
-    rc=$?; echo "pmcbench pass [$grp] rc=$rc; rows: $(cat $O/pmcb/$n/*/*counter_collection.csv 2>/dev/null | wc -l); bench line: $(grep -o '"value": [0-9.]*' $O/pmcb/$n.log | head -1)"
+    rc=$?; echo "pmcbench pass [$grp] rc=$rc; rows: $(find $O/pmcb/$n -name "*counter_collection.csv" -exec cat {} + 2>/dev/null | wc -l); bench line: $(grep -o '"value": [0-9.]*' $O/pmcb/$n.log | head -1)"
     [ $rc -ne 0 ] && tail -5 $O/pmcb/$n.log | cut -c1-300
   done
   SGMSE_PROFILE_DUMP=1 timeout 300 python bench.py --batch $PB --N 2 --steps 1 --warmup 1 --no-cpu-baseline --no-others > /dev/null 2> $O/pmcb/dump.txt
