@@ -132,6 +132,9 @@ __device__ __forceinline__ void conv_tile_of(const ConvArgs& p, int t, int nt, i
   }
 }
 
+#ifndef SGMSE_SPLITK_FRAGMENT_MAJOR
+#define SGMSE_SPLITK_FRAGMENT_MAJOR 1
+#endif
 constexpr int kAmaxSpread = 64;
 
 // ragged launch (ConvArgs::rag_w): point this workgroup's argument copy at utterance b; false = the tile lies beyond its width
@@ -532,6 +535,43 @@ __device__ __forceinline__ void conv_splitk_sum(const ConvArgs& p, int nchunks, 
   const int H = p.H, W = p.W;
   const size_t slab = conv_partial_slab(p, H, W);
   const int x = tx * 32 + l31;
+  // Up to 8 chunks (what the engine's chunking produces for 256 / 512 input channels): fragment loop OUTSIDE, the 16 x nchunks loads of one
+  // fragment in flight together -- FC*FP memory round trips per workgroup instead of nchunks (round 5: the reduce launches of the coarse
+  // levels are 53 x 17 us of a batch-1 evaluation, most of it the chunk loop's serial round trips to partial sums that the chunk
+  // workgroups have just written through to memory).  An element still sums its chunks in chunk order: the same bits.
+  if (SGMSE_SPLITK_FRAGMENT_MAJOR && nchunks <= 8 && slab < ((size_t)1 << 28)) {      // (element offsets inside a slab fit 32 bits)
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+      for (int j = 0; j < FP; ++j) {
+        const int y = ty * ROWS + wp * FP + j;
+        unsigned off[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+          const bool ok = co < p.Cout && y < H && x < W;
+          off[r] = ok ? (unsigned)(((b * p.Cout + co) * H + y) * W + x) : 0u;      // clamped, unpredicated
+        }
+        f32x16 v[8];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) {
+          const float* pz = p.partial + (size_t)(z < nchunks ? z : 0) * slab;     // (chunks past the end: re-read chunk 0, never added)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[z][r] = pz[off[r]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = v[0][r];
+#pragma unroll
+        for (int z = 1; z < 8; ++z) {
+          if (z < nchunks) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] + v[z][r];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  } else
   // chunk loop OUTSIDE: the FC*FP*16 loads of one chunk are independent and in flight together; an element still sums its
   // chunks in chunk order (what makes split-K bit-identical to the chunked single-workgroup run)
   for (int z = 0; z < nchunks; ++z) {
