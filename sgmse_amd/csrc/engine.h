@@ -20,6 +20,9 @@
 #include "kernels_attn_misc.h"
 #include "kernels_stft.h"
 
+#ifndef SGMSE_NIN_PACKED32
+#define SGMSE_NIN_PACKED32 1
+#endif
 namespace sgmse {
 
 struct EngineError : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -988,6 +991,17 @@ class Engine {
       for (int s = 0; s < nsrc; ++s) pa.src[s] = Wp(pre + "NIN_" + std::to_string(which[s]) + ".W");
       DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), stream_, pa);
       c.packed = pk;
+      // (round 5) the 32-channel-tile layout too, as make_conv does: the attention projections sit at the 16 x 32 and 4 x 8 levels, where
+      // conv() runs the fp32 layers on 32-channel tiles with chunked accumulation and, at small batches, split-K -- without this layout
+      // q|k|v and the output projection stayed on 128-channel tiles: 24 / 8 workgroups running 16 serial K-stages at batch 1
+      // (31 / 30 us per launch against 18 us for the 1x1 shortcut of the same size, profiles/r05_prof_dump_b1.txt)
+      if (pl.co_t > 32 && SGMSE_NIN_PACKED32) {
+        const size_t ne32 = packed_weight_elems(1, C, c.cout, 32);
+        float* pk32 = static_cast<float*>(dev_alloc_w(ne32 * 4));
+        PackArgs pb = pa; pb.co_t = 32; pb.dst = pk32; pb.total = ne32;
+        DRT_LAUNCH(pack_weights_kernel, dim3((unsigned)((ne32 + 255) / 256)), dim3(256), stream_, pb);
+        c.packed32 = pk32;
+      }
     }
     if (split_mode_ && conv_split_eligible(1, C, 0, c.cout)) {
       c.split_mode = 1;
