@@ -652,3 +652,37 @@ def test_three_rank_directory_job_balanced_by_frames_with_an_edm_checkpoint(emu,
     for i in range(len(lengths)):
         a, b = wavfile.read(str(tmp_path / "o1" / f"f{i}.wav"))[1], wavfile.read(str(tmp_path / "o3" / f"f{i}.wav"))[1]
         assert np.array_equal(a, b) and np.isfinite(a).all() and np.abs(a).max() > 0, i
+
+
+def test_bench_reads_the_committed_counters_of_its_own_run(tmp_path):
+    """bench.py::pmc_of_the_bench_run takes roofline.traffic / mfma_busy from profiles/*pmc_bench_b<batch>.json (counters of the bench
+    command's own launches, tools/summarize_pmc_bench.py) and falls back to nothing when no file matches; the summariser turns rocprofv3
+    counter_collection CSVs + a per-launch listing into that file."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prefix = bench.DOMINANT[3][3]
+    got = bench.pmc_of_the_bench_run(prefix, 32)
+    assert got, "profiles/ holds no *pmc_bench_b32.json"
+    assert 0.2 < got["mfma_busy"] < 1.0 and 1e9 < got["traffic"] < 1e10 and "pmc_bench_b32.json" in got["pmc_source"]
+    assert 1.0 < got["effective_clock_ghz"] < 2.5 and got["valu_per_mfma"] > 1.0
+    assert bench.pmc_of_the_bench_run(prefix, 7) == {}
+    # the summariser on a synthetic pass: two launches of one kernel, one counter group per directory
+    rows = "Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n"
+    k = '"void sgmse::conv3x3_wino_kernel<8, 1, 0, 0, 0>(sgmse::ConvArgs)"'
+    d1, d2 = tmp_path / "a" / "host", tmp_path / "b" / "host"
+    d1.mkdir(parents=True); d2.mkdir(parents=True)
+    (d1 / "1_counter_collection.csv").write_text(rows + "".join(
+        f"{i},{k},{n},{v},{1000 * i},{1000 * i + 2000000}\n" for i in (1, 2)
+        for n, v in (("SQ_VALU_MFMA_BUSY_CYCLES", 2.0e9), ("GRBM_GUI_ACTIVE", 8 * 4.0e6), ("SQ_INSTS_VALU", 6e6), ("SQ_INSTS_MFMA", 1e6))))
+    (d2 / "1_counter_collection.csv").write_text(rows + "".join(f"{i},{k},FETCH_SIZE,1000000,{1000 * i},{1000 * i + 2000000}\n" for i in (1, 2)))
+    dump = tmp_path / "dump.txt"
+    dump.write_text("[sgmse-prof] conv3x3-wino 128->128 @32x256x512 +res +gn 3.4 ms 1.0 Gwork/s\n")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc_bench.py"), str(tmp_path / "a"), str(tmp_path / "b"),
+                          "--dump", str(dump)], capture_output=True, text=True, check=True).stdout
+    e = json.loads(out)["sgmse::conv3x3_wino_kernel<8, 1, 0, 0, 0>"]
+    assert e["launches"] == 2 and abs(e["mfma_busy"] - 2.0e9 / (4.0e6 * 1024)) < 1e-9 and abs(e["valu_per_mfma"] - 6.0) < 1e-9
+    assert e["fetch_bytes_per_launch"] == 1000000 * 1024.0 and abs(e["effective_clock_ghz"] - 2.0) < 1e-9
+    assert e["algorithmic_bytes_per_launch"] == 4.0 * 32 * 256 * 512 * (128 + 128 + 128) + 4.0 * 128 * 128 * 9
