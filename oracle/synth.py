@@ -41,13 +41,16 @@ def synth_params(cfg: NetCfg, seed: int = 0) -> Dict[str, torch.Tensor]:
     return out
 
 
-_GN_CACHE: Dict[int, set] = {}
+_GN_CACHE: Dict[str, set] = {}
 
 
 def _is_gn(name: str, cfg: NetCfg) -> bool:
     """Stand-alone nn.GroupNorm entries of all_modules (ncsnpp.py:218,230,249)."""
     from .ncsnpp_oracle import build_layout
-    key = id(cfg)
+    # keyed by the configuration's VALUE (round 5: it was keyed by id(cfg) -- ids are reused once an object is collected, so a later,
+    # different configuration could inherit another one's GroupNorm set and draw its parameters from the wrong distributions: a rare,
+    # order-dependent failure of whichever oracle test came next)
+    key = repr(cfg)
     if key not in _GN_CACHE:
         _GN_CACHE[key] = {f"all_modules.{m.idx}" for m in build_layout(cfg) if m.kind == "gn"}
     return name.rsplit(".", 1)[0] in _GN_CACHE[key]
