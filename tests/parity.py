@@ -519,15 +519,17 @@ def check_sampler_golden(dev, tag, batch=None, use_graph=True):
         assert nfe == N
     else:
         N, corr = int(z["N"]), str(z["corrector"])
-        ndraws = 1 + N * (2 if corr != "none" else 1)
+        csteps = int(z["corrector_steps"]) if "corrector_steps" in z.files else 1        # (pc_N4_c2: correctors.py:69-81 looped twice)
+        ndraws = 1 + N * ((csteps + 1) if corr != "none" else 1)
         noise = replay_noise(y.shape, ndraws)
         if batch is not None:
             y, ref, noise = y[:batch], ref[:batch], noise[:, :batch]
-        sampler = m.get_pc_sampler(str(z["predictor"]), corr, y.to(dev), N=N, snr=float(z["snr"]),
+        sampler = m.get_pc_sampler(str(z["predictor"]), corr, y.to(dev), N=N, snr=float(z["snr"]), corrector_steps=csteps,
                                    noise=noise.contiguous().to(dev), use_graph=use_graph)
         out, nfe = sampler()
-        assert nfe == int(z["nfe"])
+        assert nfe == int(z["nfe"]) == N * ((csteps if corr != "none" else 0) + 1)
     assert rel_l2(out.cpu(), ref) < SAMPLER_TOL, tag
+    return out
 
 
 def check_front_end(dev, fc, L):

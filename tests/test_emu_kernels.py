@@ -217,6 +217,10 @@ def test_pc_sampler_matches_reference(emu):
     P.check_sampler_golden(emu, "pc_N4", batch=1)
 
 
+def test_pc_sampler_with_two_corrector_steps_matches_reference(emu):
+    P.check_sampler_golden(emu, "pc_N4_c2", batch=1)
+
+
 @pytest.mark.skipif(not SLOW, reason="SGMSE_SLOW=1")
 @pytest.mark.slow
 @pytest.mark.parametrize("tag", ["pnone_N6", "pfode_N6"])

@@ -194,9 +194,17 @@ def test_forward_matches_reference(hip, name):
     P.check_forward_golden(hip, name)
 
 
-@pytest.mark.parametrize("tag", ["pc_N4", "pc_N30", "pnone_N6", "pfode_N6", "lang_N4"])
+@pytest.mark.parametrize("tag", ["pc_N4", "pc_N30", "pnone_N6", "pfode_N6", "lang_N4", "pc_N4_c2"])
 def test_samplers_match_reference(hip, tag):
     P.check_sampler_golden(hip, tag)
+
+
+def test_two_corrector_steps_graph_equals_eager(hip):
+    """--corrector_steps 2 of the drop-in script (enhancement.py:26,82; correctors.py:69-81): the captured step holds two corrector
+    updates with their own noise draws (engine.h::pc_sample); replayed graph == eager loop bit for bit, both against the reference's run."""
+    a = P.check_sampler_golden(hip, "pc_N4_c2", use_graph=True)
+    b = P.check_sampler_golden(hip, "pc_N4_c2", use_graph=False)
+    assert torch.equal(a, b)
 
 
 def test_sampler_48k_variant_against_oracle(hip):

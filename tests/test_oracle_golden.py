@@ -60,7 +60,7 @@ def test_step_table_survey_appendix_b():
     assert abs(float(tab["ald_noise"][25]) - 0.153482258) < 1e-7
 
 
-@pytest.mark.parametrize("tag", ["pc_N4", "pnone_N6", "lang_N4"])
+@pytest.mark.parametrize("tag", ["pc_N4", "pnone_N6", "lang_N4", "pc_N4_c2"])
 def test_sampler_matches_reference(tag):
     z = load(tag)
     cfg = NO.NetCfg.for_variant("ncsnpp", nf=32)
@@ -68,7 +68,8 @@ def test_sampler_matches_reference(tag):
     sde = SO.OUVE(1.5, 0.05, 0.5, int(z["N"]))
     out, nfe = SO.pc_sample(sde, lambda a, b, c: NO.score_fn(P, cfg, a, b, c), torch.from_numpy(z["y"]),
                             SO.NoiseReplay(int(z["noise_seed"])), eps=0.03, snr=float(z["snr"]),
-                            corrector=str(z["corrector"]), predictor=str(z["predictor"]))
+                            corrector=str(z["corrector"]), predictor=str(z["predictor"]),
+                            corrector_steps=int(z["corrector_steps"]) if "corrector_steps" in z.files else 1)
     assert nfe == int(z["nfe"])
     assert rel_l2(out, z["out"]) < 1e-4
 
