@@ -55,6 +55,10 @@ DOMINANT = {   # conv split mode -> (kernel, effective peak, how the peak is der
         "void sgmse::conv3x3_wino_kernel<8, 1, 0"),
 }
 HBM_PEAK_GBS = 8000.0
+# how much slower the reference's own NCSNpp module is than the oracle port timed by cpu_baseline (see there)
+PORT_VS_REFERENCE = {"factor": 1.70, "calibration": "tools/port_vs_reference.py in the build container, 2026-09-30: reference / port seconds per "
+                     "[1,4,256,512] evaluation = 4.01 / 2.42 and 4.23 / 2.35 (8 threads), 6.64 / 3.90 (4 threads); /root/reference is not on the GPU box",
+                     "threads_of_the_calibration": [8, 4], "reference_path": "sgmse/backbones/ncsnpp.py:256-419"}
 
 
 def parse():
@@ -186,14 +190,21 @@ def cpu_baseline(state, n_evals, N, snr, frames=512):
         FO.istft(FO.spec_back(xm[0, 0], fc), fc, 64000)
         t_back = time.perf_counter() - t0
     per_utt = t_front + t_back + 2 * N * t_eval + N * t_glue
+    # Calibration of the port against the module it restates (tools/port_vs_reference.py: the imported reference NCSNpp and the port
+    # on the same [1,4,256,512] evaluation, interleaved runs, build container, 2026-09-30): 8 threads 4.01 s vs 2.42 s (1.66), repeat
+    # 4.23 vs 2.35 (1.80); 4 threads 6.64 vs 3.90 (1.70).  The ratio does not move with the thread count (the container has 8 CPUs:
+    # 16 threads cannot be measured there), so the same factor is applied to the box's `cores` threads.
+    factor = PORT_VS_REFERENCE["factor"]
     return {"value": 1.0 / per_utt, "unit": "utterances/s", "cores": cores, "kind": "port",
             "sample": f"{n_evals} timed NCSN++ evaluations at [1,4,256,{frames}] after 1 warm-up, scaled x{512 // frames} to the "
                       f"512-frame utterance ({t_eval:.2f} s per full evaluation on {cores} threads) + front-end + one PC step of "
                       f"sampler glue, extrapolated to {2 * N} evaluations; B=1, 4 s utterance",
             "seconds_per_eval": t_eval, "rtf": per_utt / 4.0,
-            "port_vs_reference": "calibration from the build container (8 threads, same [1,4,256,512] evaluation, interleaved runs): the imported "
-                                 "reference NCSNpp takes 3.07 s per evaluation, this port 2.33 s -- the port is 1.32x FASTER than the reference "
-                                 "module it restates (no autograd bookkeeping, fused padding), so the reference's own CPU rate is about value / 1.32"}
+            "reference_equivalent": {"value": 1.0 / (per_utt * factor), "unit": "utterances/s", "rtf": per_utt * factor / 4.0,
+                                     "seconds_per_eval": t_eval * factor, **PORT_VS_REFERENCE},
+            "port_vs_reference": f"the port is {factor:.2f}x FASTER than the reference module it restates (no autograd bookkeeping, fused padding, "
+                                 "FIR as closed-form taps instead of upfirdn2d_native's single-channel convolutions): the reference's own CPU "
+                                 "rate on this box is reference_equivalent.value"}
 
 
 def hbm_traffic_of_dominant_kernel(prefix):
@@ -212,31 +223,71 @@ def hbm_traffic_of_dominant_kernel(prefix):
     return None, "no committed PMC profile holds the dominant kernel"
 
 
-def pmc_of_the_bench_run(prefix, batch):
-    """Counters of THIS command's own launches of the dominant kernel (tools/gpu_visit.sh STEPS=pmcbench: rocprofv3 --pmc passes over
-    `bench.py --steps 1 --warmup 1 --no-others --no-cpu-baseline --no-profile` at the benched batch, one pass per counter group,
-    summarised by tools/summarize_pmc_bench.py into profiles/*pmc_bench_b<batch>.json).  When the file is there, `traffic` is its
-    FETCH_SIZE + WRITE_SIZE per launch (mean over the dominant kernel's launches of the run) and `mfma_busy` its
-    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE); otherwise the micro-benchmark figures stay and say so."""
+def pmc_of_the_bench_run(prefix, batch, workload):
+    """COMMITTED counters of this command's launches of the dominant kernel (tools/gpu_visit.sh STEPS=pmcbench: rocprofv3 --pmc passes over
+    `bench.py --batch B --steps 1 --warmup 0 --N 2 --no-graph ...`, one pass per counter group, summarised by
+    tools/summarize_pmc_bench.py into profiles/*pmc_bench_b<batch>.json).  They are counters of an EARLIER execution of the command, not of
+    the process that prints the line, so the summary's `_meta` (command, workload, batch, git commit, hash of the kernel sources) decides
+    whether they apply: only a file of the same workload and batch is used, and `pmc_matches_this_build` says whether the kernel sources
+    have changed since.  `traffic` = calibrated FETCH_SIZE + WRITE_SIZE per launch (the calibration rows of the same pass, `_meta` /
+    `fetch_calibration`); `attention` = the same passes' rows of attn_core_kernel (MFMA utilisation of the QK^T / PV contractions)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_bench_b{batch}.json")))
-    if not files:
-        return {}
-    d = json.load(open(files[-1]))
-    row = next((v for k, v in d.items() if k.startswith(prefix.replace("void ", ""))), None)
-    if not row:
-        return {}
-    upd = {"pmc_source": f"{os.path.basename(files[-1])}: rocprofv3 --pmc passes over this command at batch {batch} "
-                         f"({row.get('launches')} launches of the dominant kernel instantiation)"}
-    if row.get("hbm_bytes_per_launch") is not None:
-        upd["traffic"] = row["hbm_bytes_per_launch"]
-        upd["traffic_source"] = upd["pmc_source"]
-        upd["traffic_note"] = (f"FETCH_SIZE + WRITE_SIZE per launch, mean over the run's launches; algorithmic bytes per launch (mean) "
-                               f"{row.get('algorithmic_bytes_per_launch')}")
-    for k in ("mfma_busy", "effective_clock_ghz", "valu_per_mfma", "lds_conflict_frac"):
-        if row.get(k) is not None:
-            upd[k] = row[k]
-    return upd
+    for f in reversed(files):
+        d = json.load(open(f))
+        meta = d.get("_meta") or {}
+        if meta.get("workload", "pc16k") != workload or int(meta.get("batch", batch)) != batch:
+            continue
+        row = next((v for k, v in d.items() if k.startswith(prefix.replace("void ", ""))), None)
+        if not row:
+            continue
+        src = (f"{os.path.basename(f)}: committed rocprofv3 --pmc passes over `{meta.get('command', 'bench.py --batch %d --N 2 --no-graph' % batch)}` "
+               f"at commit {meta.get('commit', '?')} ({row.get('launches')} launches of the dominant kernel instantiation)")
+        upd = {"pmc_source": src, "pmc_source_hash": meta.get("source_hash"), "pmc_matches_this_build": meta.get("source_hash") == source_hash()}
+        if row.get("hbm_bytes_per_launch") is not None:
+            upd["traffic"] = row["hbm_bytes_per_launch"]
+            upd["traffic_source"] = src
+            upd["traffic_note"] = (f"calibrated FETCH_SIZE + WRITE_SIZE per launch, mean over the run's launches; raw counters "
+                                   f"{row.get('fetch_bytes_per_launch_raw')} + {row.get('write_bytes_per_launch_raw')}; algorithmic bytes per "
+                                   f"launch (mean) {row.get('algorithmic_bytes_per_launch')}")
+            upd["fetch_calibration"] = d.get("_calibration")
+        for k in ("mfma_busy", "effective_clock_ghz", "valu_per_mfma", "lds_conflict_frac"):
+            if row.get(k) is not None:
+                upd[k] = row[k]
+        att = next((v for k, v in d.items() if "attn_core_kernel" in k), None)
+        if att:
+            upd["attention"] = {k: att.get(k) for k in ("launches", "mean_duration_us_under_pmc", "mfma_busy", "effective_clock_ghz", "valu_per_mfma",
+                                                         "lds_conflict_frac") if att.get(k) is not None}
+            upd["attention"]["kernel"] = "attn_core_kernel (QK^T and PV on v_mfma_f32_32x32x2_f32; layerspp.py:82-88)"
+        return upd
+    return {}
+
+
+CALIB_BYTES = 1 << 30
+
+
+def pmc_calibration_launches(dev):
+    """SGMSE_PMC_CALIB=1 (tools/gpu_visit.sh STEPS=pmcbench): four launches of known size -- a coalesced 1 GiB read and write stream at
+    8 and at 16 bytes per lane (calib_stream_kernel) -- in front of the run, so that the FETCH_SIZE / WRITE_SIZE pass over THIS command
+    holds its own calibration rows (tools/summarize_pmc_bench.py divides the known bytes by what the counter reported for them)."""
+    from sgmse_amd import _lib
+    ctx = _lib.Context(str(dev))
+    for mode in (0, 1):
+        for width in (8, 16):
+            ms = ctx.calib_stream(mode, width, CALIB_BYTES)
+            print(f"[pmc-calib] {'write' if mode else 'read'} {width} B/lane: {CALIB_BYTES} bytes in {ms:.3f} ms = {CALIB_BYTES / ms / 1e9:.2f} TB/s", file=sys.stderr)
+    del ctx
+
+
+def source_hash():
+    """sha256 over the kernel sources the library is built from: ties a committed counter summary to the build it was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "sgmse_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "sgmse_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parity_leg(env):
@@ -335,9 +386,16 @@ def measure(env, a, workload, batch, steps, warmup, sampler=None, N=None, snr=No
     net_kw = dict(nf=32) if emu else {}                                                    # full-size network unless --test-emulator
     model = ScoreModel(wl["backbone"], "ouve", N=N, sr=wl["sr"], **wl["sde"], **wl["front"], **net_kw)   # random init
     model.to(dev).eval()
-    bcast_ms = None
+    bcast_ms = comm_setup_ms = None
     if world > 1:
+        # The first collective of a process carries RCCL's lazy communicator set-up (0.5-3 s at 8 ranks): one 4-byte broadcast takes
+        # it (reported apart), so that weight_broadcast_ms is the 262 MB transfer over xGMI the north star names and nothing else.
         env.sync()
+        t0 = time.perf_counter()
+        dist.broadcast(torch.zeros(1, device=dev), src=0)
+        env.sync()
+        comm_setup_ms = (time.perf_counter() - t0) * 1e3
+        env.fence()
         t0 = time.perf_counter()
         broadcast_backbone_weights(model.dnn, src=0)
         env.sync()
@@ -409,6 +467,8 @@ def measure(env, a, workload, batch, steps, warmup, sampler=None, N=None, snr=No
     out["graph_captures_rank0"] = ctx.graph_captures()   # 1: the seed changes per step, the captured step does not
     if world > 1:
         out["weight_broadcast_ms"] = bcast_ms
+        out["weight_broadcast_gbps"] = ctx.param_count() * 4 / (bcast_ms * 1e-3) / 1e9 if bcast_ms else None
+        out["communicator_setup_ms"] = comm_setup_ms     # the 4-byte warm-up broadcast: RCCL's lazy init, once per process
         out["per_rank_utt_per_s"] = [batch * steps / t for t in per_rank]
         out["collective_backend"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                      "note": "the only collective: one weight broadcast before the timed region"}
@@ -434,7 +494,7 @@ def measure(env, a, workload, batch, steps, warmup, sampler=None, N=None, snr=No
         if wino:
             out["roofline"]["peak_of_the_direct_form"] = MFMA16_PEAK_TFLOPS / 3
             out["roofline"]["frac_of_the_direct_form"] = ach / (MFMA16_PEAK_TFLOPS / 3)
-        out["roofline"].update(pmc_of_the_bench_run(prefix, batch))
+        out["roofline"].update(pmc_of_the_bench_run(prefix, batch, workload))
         classes = {}
         for k, v in prof.items():
             rate = v["work"] / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
@@ -452,6 +512,8 @@ def main():
     if a.batch == 32 and wl["batch"] != 32:
         a.batch = wl["batch"]
     env = Env(a)
+    if os.environ.get("SGMSE_PMC_CALIB") and env.rank == 0 and not env.emu:
+        pmc_calibration_launches(env.dev)
     out, model = measure(env, a, a.workload, a.batch, a.steps, a.warmup, sampler=a.sampler, N=a.N, snr=a.snr, seconds=a.seconds, want_power=True)
     headline = (a.workload == "pc16k" and a.batch == 32 and a.sampler in (None, "pc") and a.N in (None, 30) and a.seconds == 4.0)
     if env.rank == 0 and not a.no_cpu_baseline and env.world == 1 and a.workload == "pc16k" and not env.emu:

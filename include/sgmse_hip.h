@@ -170,6 +170,10 @@ int sgmse_profile_forward(sgmse_ctx* ctx, const void* xy, const float* t, void* 
  * fused = 1 adds the GroupNorm-affine+SiLU producer and the bias/residual/scale epilogue.  synchronises */
 int sgmse_bench_conv(sgmse_ctx* ctx, int ks, int B, int Cin, int Cout, int H, int W, int variant, int iters, int fused,
                      float* ms);
+/* measurement only: ONE launch of a coalesced stream of exactly total_bytes (mode 0: read, 1: write; bytes_per_lane 8 or 16) on the
+ * context's stream, so that the FETCH_SIZE / WRITE_SIZE counters of a rocprofv3 --pmc pass can be calibrated against a known byte
+ * count in the pass that reads them (tools/gpu_visit.sh STEPS=pmcbench; nothing in the reference corresponds).  synchronises */
+int sgmse_calib_stream(sgmse_ctx* ctx, int mode, int bytes_per_lane, long long total_bytes, float* ms);
 int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out);
 /* Noise-stream ids (host array, one per utterance) for the NEXT sgmse_pc_sample / sgmse_sb_sample call of batch size n with
  * in-kernel (Philox) noise: an utterance's draws depend on (seed, stream id, element index inside the utterance, draw index)

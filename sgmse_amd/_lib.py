@@ -70,6 +70,7 @@ _SIGS = {
     "sgmse_op_attention": (_I, [_P, _P, _P, _I, _I, _I]),
     "sgmse_profile_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(_I)]),
     "sgmse_bench_conv": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
+    "sgmse_calib_stream": (_I, [_P, _I, _I, C.c_longlong, C.POINTER(_F)]),
     "sgmse_arena_bytes": (_I, [_P, C.POINTER(_LL)]),
     "sgmse_graph_captures": (_I, [_P, C.POINTER(_I)]),
     "sgmse_graph_updates": (_I, [_P, C.POINTER(_I)]),
@@ -415,6 +416,13 @@ class Context:
         ms = _F(0)
         self.use_current_stream()
         self.check(self.lib.sgmse_bench_conv(self.h, ks, B, Cin, Cout, H, W, variant, iters, int(fused), C.byref(ms)))
+        return ms.value
+
+    def calib_stream(self, mode: int, bytes_per_lane: int, total_bytes: int) -> float:
+        """Measurement only: one launch of a known-size coalesced read (mode 0) / write (mode 1) stream; ms of the launch."""
+        ms = _F(0)
+        self.use_current_stream()
+        self.check(self.lib.sgmse_calib_stream(self.h, int(mode), int(bytes_per_lane), int(total_bytes), C.byref(ms)))
         return ms.value
 
     def conv_winograd(self) -> bool:

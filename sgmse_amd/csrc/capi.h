@@ -208,6 +208,11 @@ int sgmse_bench_conv(sgmse_ctx* ctx, int ks, int B, int Cin, int Cout, int H, in
   return sg_guard(ctx, [&](sgmse::Engine& e) { *ms = e.bench_conv(ks, B, Cin, Cout, H, W, variant, iters, fused); });
 }
 
+int sgmse_calib_stream(sgmse_ctx* ctx, int mode, int bytes_per_lane, long long total_bytes, float* ms) {
+  SG_ARG(ctx, ms != nullptr && total_bytes > 0, "bad arguments");
+  return sg_guard(ctx, [&](sgmse::Engine& e) { *ms = e.calib_stream(mode, bytes_per_lane, (size_t)total_bytes); });
+}
+
 int sgmse_arena_bytes(sgmse_ctx* ctx, long long* out) {
   SG_ARG(ctx, out != nullptr, "out is null");
   return sg_guard(ctx, [&](sgmse::Engine& e) { *out = (long long)e.arena_bytes(); });

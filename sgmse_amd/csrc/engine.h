@@ -20,9 +20,6 @@
 #include "kernels_attn_misc.h"
 #include "kernels_stft.h"
 
-#ifndef SGMSE_NIN_PACKED32
-#define SGMSE_NIN_PACKED32 1
-#endif
 namespace sgmse {
 
 struct EngineError : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -183,6 +180,24 @@ __global__ __launch_bounds__(256) void fill_random_kernel(float* dst, size_t n, 
   uint32_t h = (uint32_t)i * 2654435761u ^ seed;
   h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
   dst[i] = (float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f;
+}
+
+// Measurement only (sgmse_calib_stream): a stream of KNOWN size for calibrating the FETCH_SIZE / WRITE_SIZE counters in the run that
+// reads them (MI355X_MICROARCH.md, HBM: gfx950's FETCH_SIZE under-reports coalesced streams by a width-dependent factor).  VEC = floats
+// per lane and access (2: the 8-byte column pairs of the Winograd kernel's staging, 4: its 16-byte weight fragments); consecutive lanes
+// read consecutive elements, a workgroup walks a contiguous chunk.  WRITE = 1: the same stream stored instead of loaded.
+template <int VEC, int WRITE>
+__global__ __launch_bounds__(256) void calib_stream_kernel(float* buf, size_t nvec, float* sink) {
+  struct alignas(VEC * 4) vec_t { float v[VEC]; };
+  vec_t* p = reinterpret_cast<vec_t*>(buf);
+  const size_t per = (nvec + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < nvec ? lo + per : nvec;
+  float acc = 0.f;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+    if constexpr (WRITE) { vec_t v; for (int k = 0; k < VEC; ++k) v.v[k] = (float)(i & 1023); p[i] = v; }
+    else { const vec_t v = p[i]; for (int k = 0; k < VEC; ++k) acc += v.v[k]; }
+  }
+  if (!WRITE && acc == 123456.789f) sink[0] = acc;
 }
 
 // [cin][cout] -> [cout][cin]
@@ -772,6 +787,29 @@ class Engine {
     return ms;
   }
 
+  // Measurement only: one launch of a known-size stream (calib_stream_kernel) for the counter calibration of tools/gpu_visit.sh
+  // STEPS=pmcbench.  mode 0 = read, 1 = write; bytes_per_lane 8 or 16.  Returns ms of the launch.
+  float calib_stream(int mode, int bytes_per_lane, size_t total_bytes) {
+    SG_REQUIRE((bytes_per_lane == 8 || bytes_per_lane == 16) && (mode == 0 || mode == 1) && total_bytes >= 4096, "calib_stream: bad arguments");
+    float* buf = static_cast<float*>(dev_alloc_tmp(total_bytes + 256));
+    SG_CHECK(drt::memset_dev(buf, 0, total_bytes + 256, stream_));
+    const size_t nvec = total_bytes / (size_t)bytes_per_lane;
+    drt::event_t e0{}, e1{};
+    drt::event_create(&e0); drt::event_create(&e1);
+    drt::event_record(&e0, stream_);
+    const dim3 g(256 * 16), b(256);
+    float* sink = buf + total_bytes / 4;
+    if (bytes_per_lane == 8) { if (mode) DRT_LAUNCH((calib_stream_kernel<2, 1>), g, b, stream_, buf, nvec, sink); else DRT_LAUNCH((calib_stream_kernel<2, 0>), g, b, stream_, buf, nvec, sink); }
+    else { if (mode) DRT_LAUNCH((calib_stream_kernel<4, 1>), g, b, stream_, buf, nvec, sink); else DRT_LAUNCH((calib_stream_kernel<4, 0>), g, b, stream_, buf, nvec, sink); }
+    drt::event_record(&e1, stream_);
+    drt::event_sync(&e1);
+    const float ms = drt::event_elapsed_ms(e0, e1);
+    check_launch();
+    drt::event_destroy(&e0); drt::event_destroy(&e1);
+    free_tmp(buf);
+    return ms;
+  }
+
   // per-kernel-class timing of one forward (eager, events on this stream); fills ms per class
   enum { TC_CONV3_BIG = 0, TC_CONV3, TC_CONV1, TC_DIRECT, TC_GN, TC_FIR, TC_ATTN, TC_MISC, TC_COUNT };
   // work[] = algorithmic FLOPs for the conv/attention classes, algorithmic bytes (each operand read once, each result
@@ -995,7 +1033,9 @@ class Engine {
       // conv() runs the fp32 layers on 32-channel tiles with chunked accumulation and, at small batches, split-K -- without this layout
       // q|k|v and the output projection stayed on 128-channel tiles: 24 / 8 workgroups running 16 serial K-stages at batch 1
       // (31 / 30 us per launch against 18 us for the 1x1 shortcut of the same size, profiles/r05_prof_dump_b1.txt)
-      if (pl.co_t > 32 && SGMSE_NIN_PACKED32) {
+      // (round 6: the compile-time switch of round 5's A/B is gone -- one build variant, the tested one.  Attention outputs changed in
+      //  their last bits with that round: fixtures of these levels recorded before it are not bit-comparable.)
+      if (pl.co_t > 32) {
         const size_t ne32 = packed_weight_elems(1, C, c.cout, 32);
         float* pk32 = static_cast<float*>(dev_alloc_w(ne32 * 4));
         PackArgs pb = pa; pb.co_t = 32; pb.dst = pk32; pb.total = ne32;

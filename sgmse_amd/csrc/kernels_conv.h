@@ -539,7 +539,9 @@ __device__ __forceinline__ void conv_splitk_sum(const ConvArgs& p, int nchunks, 
   // fragment in flight together -- FC*FP memory round trips per workgroup instead of nchunks (round 5: the reduce launches of the coarse
   // levels are 53 x 17 us of a batch-1 evaluation, most of it the chunk loop's serial round trips to partial sums that the chunk
   // workgroups have just written through to memory).  An element still sums its chunks in chunk order: the same bits.
-  if (SGMSE_SPLITK_FRAGMENT_MAJOR && nchunks <= 8 && slab < ((size_t)1 << 28)) {      // (element offsets inside a slab fit 32 bits)
+  // (element offsets fit 32 bits: inside a slab, and -- ragged launches rebase p.partial by the utterance's packed offset, so that
+  //  (b Cout + co) H W is a VIRTUAL offset of up to B slabs -- over the whole batch)
+  if (SGMSE_SPLITK_FRAGMENT_MAJOR && nchunks <= 8 && slab < ((size_t)1 << 28) && (size_t)p.B * slab < ((size_t)1 << 31)) {
 #pragma unroll
     for (int i = 0; i < FC; ++i)
 #pragma unroll
@@ -550,7 +552,7 @@ __device__ __forceinline__ void conv_splitk_sum(const ConvArgs& p, int nchunks, 
         for (int r = 0; r < 16; ++r) {
           const int co = co_blk * CO_T + (wc * FC + i) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
           const bool ok = co < p.Cout && y < H && x < W;
-          off[r] = ok ? (unsigned)(((b * p.Cout + co) * H + y) * W + x) : 0u;      // clamped, unpredicated
+          off[r] = ok ? (unsigned)((((size_t)b * p.Cout + co) * H + y) * W + x) : 0u;      // clamped, unpredicated
         }
         f32x16 v[8];
 #pragma unroll

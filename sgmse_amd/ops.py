@@ -94,13 +94,19 @@ def fir_resample(x: torch.Tensor, up: bool, in_scale: Optional[torch.Tensor] = N
 def upfirdn2d(x: torch.Tensor, kernel: torch.Tensor, up: int = 1, down: int = 1, pad: Tuple[int, int] = (0, 0)) -> torch.Tensor:
     """upfirdn2d(input[N,C,H,W], kernel[kh,kw], up, down, pad) with the same pad on both axes
     (reference op/upfirdn2d.py:148-159).  float32, float64 and float16 inputs run in their own element type like the reference op
-    (op/upfirdn2d_kernel.cu:311; half accumulates in fp32); the kernel is cast to the input's type; other dtypes go through float32."""
+    (op/upfirdn2d_kernel.cu:311 dispatches over exactly these three; half accumulates in fp32 here, in half there); any other element
+    type raises like the reference's dispatch macro does, and the kernel must live on the input's device (upfirdn2d.cpp:8,15-16: both
+    tensors are checked, neither is moved); only the kernel's element type is cast to the input's."""
     ctx = default_context(x.device)
     code = {torch.float32: 0, torch.float64: 1, torch.float16: 2}.get(x.dtype)
     if code is None:
-        x, code = x.float(), 0
+        raise ValueError(f"upfirdn2d: input dtype {x.dtype} is not supported (float32, float64, float16 -- op/upfirdn2d_kernel.cu:311)")
+    if not kernel.dtype.is_floating_point:
+        raise ValueError(f"upfirdn2d: kernel dtype {kernel.dtype} is not a floating-point type")
+    if kernel.device != x.device:
+        raise ValueError(f"upfirdn2d: kernel on {kernel.device}, input on {x.device} (the reference op checks both tensors, upfirdn2d.cpp:15-16)")
     dt = x.dtype
-    x = _lib.check_tensor(x, "input", dt, ctx.device); kernel = kernel.to(device=ctx.device, dtype=dt).contiguous()
+    x = _lib.check_tensor(x, "input", dt, ctx.device); kernel = kernel.to(dtype=dt).contiguous()
     N, Cc, H, W = x.shape
     kh, kw = kernel.shape
     Ho = (H * up + pad[0] + pad[1] - kh) // down + 1

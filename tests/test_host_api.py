@@ -664,11 +664,13 @@ def test_bench_reads_the_committed_counters_of_its_own_run(tmp_path):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     prefix = bench.DOMINANT[3][3]
-    got = bench.pmc_of_the_bench_run(prefix, 32)
+    got = bench.pmc_of_the_bench_run(prefix, 32, "pc16k")
     assert got, "profiles/ holds no *pmc_bench_b32.json"
     assert 0.2 < got["mfma_busy"] < 1.0 and 1e9 < got["traffic"] < 1e10 and "pmc_bench_b32.json" in got["pmc_source"]
     assert 1.0 < got["effective_clock_ghz"] < 2.5 and got["valu_per_mfma"] > 1.0
-    assert bench.pmc_of_the_bench_run(prefix, 7) == {}
+    assert "committed" in got["pmc_source"] and isinstance(got["pmc_matches_this_build"], bool)     # (provenance, not "this run")
+    assert bench.pmc_of_the_bench_run(prefix, 7, "pc16k") == {}
+    assert bench.pmc_of_the_bench_run(prefix, 32, "ode16k") == {}      # counters of another workload's command are not applied
     # the summariser on a synthetic pass: two launches of one kernel, one counter group per directory
     rows = "Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n"
     k = '"void sgmse::conv3x3_wino_kernel<8, 1, 0, 0, 0>(sgmse::ConvArgs)"'
@@ -677,12 +679,39 @@ def test_bench_reads_the_committed_counters_of_its_own_run(tmp_path):
     (d1 / "1_counter_collection.csv").write_text(rows + "".join(
         f"{i},{k},{n},{v},{1000 * i},{1000 * i + 2000000}\n" for i in (1, 2)
         for n, v in (("SQ_VALU_MFMA_BUSY_CYCLES", 2.0e9), ("GRBM_GUI_ACTIVE", 8 * 4.0e6), ("SQ_INSTS_VALU", 6e6), ("SQ_INSTS_MFMA", 1e6))))
-    (d2 / "1_counter_collection.csv").write_text(rows + "".join(f"{i},{k},FETCH_SIZE,1000000,{1000 * i},{1000 * i + 2000000}\n" for i in (1, 2)))
+    kc = '"void sgmse::calib_stream_kernel<2, 0>(float*, unsigned long, float*)"'      # the known-size 8 B/lane read stream of the same pass
+    ka = '"void sgmse::attn_core_kernel<4>(sgmse::AttnArgs)"'
+    (d2 / "1_counter_collection.csv").write_text(rows + "".join(f"{i},{k},FETCH_SIZE,1000000,{1000 * i},{1000 * i + 2000000}\n" for i in (1, 2))
+                                                  + f"3,{kc},FETCH_SIZE,{(1 << 30) / 1024 / 2},5000,9000\n")
+    (d1 / "2_counter_collection.csv").write_text(rows + "".join(
+        f"7,{ka},{n},{v},1000,401000\n" for n, v in (("SQ_VALU_MFMA_BUSY_CYCLES", 4.0e8), ("GRBM_GUI_ACTIVE", 8 * 8.0e5))))
     dump = tmp_path / "dump.txt"
     dump.write_text("[sgmse-prof] conv3x3-wino 128->128 @32x256x512 +res +gn 3.4 ms 1.0 Gwork/s\n")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc_bench.py"), str(tmp_path / "a"), str(tmp_path / "b"),
-                          "--dump", str(dump)], capture_output=True, text=True, check=True).stdout
-    e = json.loads(out)["sgmse::conv3x3_wino_kernel<8, 1, 0, 0, 0>"]
+                          "--dump", str(dump), "--meta", "command=bench.py --batch 32 --N 2", "workload=pc16k", "batch=32", "commit=abc1234",
+                          "source_hash=0123"], capture_output=True, text=True, check=True).stdout
+    d = json.loads(out)
+    assert d["_meta"] == {"command": "bench.py --batch 32 --N 2", "workload": "pc16k", "batch": 32, "commit": "abc1234", "source_hash": "0123"}
+    assert abs(d["_calibration"]["fetch_8B_per_lane"]["factor"] - 2.0) < 1e-9       # the counter reported half of the known gibibyte
+    e = d["sgmse::conv3x3_wino_kernel<8, 1, 0, 0, 0>"]
     assert e["launches"] == 2 and abs(e["mfma_busy"] - 2.0e9 / (4.0e6 * 1024)) < 1e-9 and abs(e["valu_per_mfma"] - 6.0) < 1e-9
-    assert e["fetch_bytes_per_launch"] == 1000000 * 1024.0 and abs(e["effective_clock_ghz"] - 2.0) < 1e-9
+    assert e["fetch_bytes_per_launch_raw"] == 1000000 * 1024.0 and e["fetch_bytes_per_launch"] == 2.0 * 1000000 * 1024.0
+    assert abs(e["effective_clock_ghz"] - 2.0) < 1e-9
+    att = d["sgmse::attn_core_kernel<4>"]
+    assert abs(att["mfma_busy"] - 4.0e8 / (8.0e5 * 1024)) < 1e-9
+    # bench.py applies such a file: calibrated traffic, its provenance, the attention row
+    import shutil
+    prof = tmp_path / "root" / "profiles"
+    prof.mkdir(parents=True)
+    (prof / "r99_pmc_bench_b32.json").write_text(out)
+    saved = bench.ROOT
+    try:
+        bench.ROOT = str(tmp_path / "root")
+        os.makedirs(os.path.join(bench.ROOT, "sgmse_amd", "csrc"))
+        got = bench.pmc_of_the_bench_run(prefix, 32, "pc16k")
+    finally:
+        bench.ROOT = saved
+    assert got["traffic"] == 2.0 * 1000000 * 1024.0 and got["fetch_calibration"]["fetch_8B_per_lane"]["factor"] == 2.0
+    assert "abc1234" in got["pmc_source"] and got["pmc_matches_this_build"] is False
+    assert abs(got["attention"]["mfma_busy"] - 4.0e8 / (8.0e5 * 1024)) < 1e-9
     assert e["algorithmic_bytes_per_launch"] == 4.0 * 32 * 256 * 512 * (128 + 128 + 128) + 4.0 * 128 * 128 * 9

@@ -37,10 +37,11 @@ rocm-smi --showproductname 2>/dev/null | head -8 > $O/gpu.txt; nproc >> $O/gpu.t
 if has smoke; then echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -2 | tee $O/${TAG}_smoke.txt; fi
 if has pytest; then
   echo "== pytest -m gpu ${PYTEST_K:+-k \"$PYTEST_K\"}"
-  timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q -s -p no:cacheprovider ${PYTEST_X:+-x} ${PYTEST_K:+-k "$PYTEST_K"} > $O/${TAG}_pytest_gpu${PYTEST_NAME:+_$PYTEST_NAME}.log 2>&1
+  timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q -s -p no:cacheprovider --durations=${PYTEST_DURATIONS:-15} ${PYTEST_X:+-x} ${PYTEST_K:+-k "$PYTEST_K"} > $O/${TAG}_pytest_gpu${PYTEST_NAME:+_$PYTEST_NAME}.log 2>&1
   echo "pytest rc=$?"; tail -3 $O/${TAG}_pytest_gpu${PYTEST_NAME:+_$PYTEST_NAME}.log | cut -c1-300
   grep -E "^(FAILED|ERROR)|Memory access|Error" $O/${TAG}_pytest_gpu${PYTEST_NAME:+_$PYTEST_NAME}.log | head -20
   grep -E "^conv_wino|^conv_split" $O/${TAG}_pytest_gpu${PYTEST_NAME:+_$PYTEST_NAME}.log | head -30
+  grep -A ${PYTEST_DURATIONS:-15} "slowest" $O/${TAG}_pytest_gpu${PYTEST_NAME:+_$PYTEST_NAME}.log | tee $O/${TAG}_pytest_gpu_durations.txt | head -20
 fi
 if has micro; then
   echo "== kernel micro-benchmark (VARIANTS=$VARIANTS SHAPES=$SHAPES FUSED=$FUSED)"
@@ -122,20 +123,25 @@ if has pmcbench; then
       python bench.py --batch $PB --steps 1 --warmup 0 --N 2 --no-others --no-cpu-baseline --no-profile > $O/pmcb/graph_probe.log 2>&1
     echo "pmcbench graph probe rc=$?; rows: $(find $O/pmcb/graph_probe -name "*counter_collection.csv" -exec cat {} + 2>/dev/null | wc -l); bench line: $(grep -o '"value": [0-9.]*' $O/pmcb/graph_probe.log | head -1)" | tee $O/${TAG}_pmc_bench_graph_probe.txt
   fi
+  # round 6: the passes also keep attn_core_kernel (MFMA utilisation of attention) and the known-size calibration streams that
+  # SGMSE_PMC_CALIB=1 puts in front of the run (calibrated FETCH_SIZE / WRITE_SIZE: tools/summarize_pmc_bench.py)
+  PMCB_CMD="bench.py --batch $PB $PMCB_BASE --no-others --no-cpu-baseline --no-profile $PMCB_ARGS"
   for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
     n=$(echo $grp | cut -d' ' -f1)
-    timeout ${PMCB_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "${PMCB_REGEX:-conv3x3_wino_kernel}" --output-format csv -d $O/pmcb/$n -o pmc -- \
-      python bench.py --batch $PB $PMCB_BASE --no-others --no-cpu-baseline --no-profile $PMCB_ARGS > $O/pmcb/$n.log 2>&1
+    SGMSE_PMC_CALIB=1 timeout ${PMCB_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "${PMCB_REGEX:-conv3x3_wino|attn_core_kernel|calib_stream_kernel}" --output-format csv -d $O/pmcb/$n -o pmc -- \
+      python $PMCB_CMD > $O/pmcb/$n.log 2>&1
     rc=$?; echo "pmcbench pass [$grp] rc=$rc; rows: $(find $O/pmcb/$n -name "*counter_collection.csv" -exec cat {} + 2>/dev/null | wc -l); bench line: $(grep -o '"value": [0-9.]*' $O/pmcb/$n.log | head -1)"
     [ $rc -ne 0 ] && tail -5 $O/pmcb/$n.log | cut -c1-300
   done
   SGMSE_PROFILE_DUMP=1 timeout 300 python bench.py --batch $PB --N 2 --steps 1 --warmup 1 --no-cpu-baseline --no-others > /dev/null 2> $O/pmcb/dump.txt
-  python tools/summarize_pmc_bench.py $O/pmcb/SQ_VALU_MFMA_BUSY_CYCLES $O/pmcb/SQ_LDS_BANK_CONFLICT $O/pmcb/FETCH_SIZE $O/pmcb/WRITE_SIZE --dump $O/pmcb/dump.txt > $O/${TAG}_pmc_bench_b${PB}.json 2>$O/pmcb/summ.err
+  SRC_HASH=$(python -c "import bench; print(bench.source_hash())" 2>/dev/null)
+  python tools/summarize_pmc_bench.py $O/pmcb/SQ_VALU_MFMA_BUSY_CYCLES $O/pmcb/SQ_LDS_BANK_CONFLICT $O/pmcb/FETCH_SIZE $O/pmcb/WRITE_SIZE --dump $O/pmcb/dump.txt \
+    --meta "command=$PMCB_CMD" workload=${PMCB_WORKLOAD:-pc16k} batch=$PB "commit=${COMMIT:-unknown}" "source_hash=$SRC_HASH" > $O/${TAG}_pmc_bench_b${PB}.json 2>$O/pmcb/summ.err
   python - <<PY
 import json
 try:
     d = json.load(open("$O/${TAG}_pmc_bench_b${PB}.json"))
-    for k, v in d.items(): print(k[:70], {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a != "counters_mean"})
+    for k, v in d.items(): print(k[:70], {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a != "counters_mean"} if isinstance(v, dict) else v)
 except Exception as e: print("pmcbench summary FAILED", e)
 PY
   rm -rf $O/pmcb/*/ 2>/dev/null
