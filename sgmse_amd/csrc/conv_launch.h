@@ -5,6 +5,7 @@
 #include "kernels_conv1x1.h"
 #include "kernels_conv_split.h"
 #include "kernels_conv_wino.h"
+#include "kernels_conv_wino2d.h"
 #include "kernels_conv_thin.h"
 
 #ifndef SGMSE_CONV_SPLIT_DEFAULT
@@ -186,6 +187,17 @@ inline void launch_conv_wino(const ConvArgs& a, drt::stream_t st, bool rows4, bo
     else if (act) DRT_LAUNCH((conv3x3_wino_kernel<8, 1, 0>), grid, dim3(512), st, a);
     else DRT_LAUNCH((conv3x3_wino_kernel<8, 0, 0>), grid, dim3(512), st, a);
   }
+}
+
+// 2-D Winograd F(2x2,3x3) x fp16x2 (kernels_conv_wino2d.h; round 6: built, verified and measured against the 1-D kernel -- not the product
+// path); a.w = fragments packed by pack_weights_wino2d_kernel.  No folded shortcut.  abl: measurement only.
+inline void launch_conv_wino2d(const ConvArgs& a, drt::stream_t st, int abl = 0) {
+  const dim3 grid(conv_grid_tiles(a, 4), a.Cout / 128, 1);
+  const bool act = a.in_scale && a.in_act;
+  if (abl == 8) { DRT_LAUNCH((conv3x3_wino2d_kernel<1, 8>), grid, dim3(512), st, a); return; }
+  if (abl == 16) { DRT_LAUNCH((conv3x3_wino2d_kernel<1, 16>), grid, dim3(512), st, a); return; }
+  if (act) DRT_LAUNCH((conv3x3_wino2d_kernel<1>), grid, dim3(512), st, a);
+  else DRT_LAUNCH((conv3x3_wino2d_kernel<0>), grid, dim3(512), st, a);
 }
 
 // exact-fp32 VALU kernel of the C -> 4 pyramid convolutions (kernels_conv_thin.h); a.w = weights packed by pack_weights_thin_kernel

@@ -575,6 +575,17 @@ class Engine {
       launch_conv_thin(a, stream_);
       SG_CHECK(drt::stream_sync(stream_));
       free_tmp(const_cast<float*>(pk));
+    } else if (force_direct == 7) {                        // 2-D Winograd F(2x2,3x3) x fp16x2 (kernels_conv_wino2d.h)
+      SG_REQUIRE(ks == 3 && conv_wino_eligible(a.C1, C2, Cout, W), "op_conv2d: shape is not eligible for the 2-D Winograd kernel");
+      const float* pk = pack_wino2d(w_oihw, Cin, Cout, false, &a.co_scale);
+      a.w = pk;
+      float* bounds = input_bounds(x, a.C1, x2, C2, B, H * W);
+      const float* am2 = x2 ? bounds + (size_t)B * kAmaxSpread : nullptr;
+      float* xb = producer_bound(in_scale, in_shift, Cin, bounds, am2, B);
+      a.xbound = xb;
+      launch_conv_wino2d(a, stream_);
+      SG_CHECK(drt::stream_sync(stream_));
+      free_tmp(const_cast<float*>(pk)); free_tmp(bounds); free_tmp(xb);
     } else if (force_direct == 4 || force_direct == 5) {          // Winograd F(2,3) x fp16x2: 4 = 8-row shape, 5 = 4-row shape
       SG_REQUIRE(ks == 3 && conv_wino_eligible(a.C1, C2, Cout, W), "op_conv2d: shape is not eligible for the Winograd kernel");
       const float* pk = pack_wino(w_oihw, Cin, Cout, false, &a.co_scale);
@@ -708,9 +719,10 @@ class Engine {
       variant &= 4095;
     }
     const bool wino = variant >= 0 && (variant & 1024);          // measurement: the Winograd F(2,3) x fp16x2 kernel (bit 23: its 4-row shape)
+    const bool wino2d = variant >= 0 && (variant & 2048) && !wino;   // ... the 2-D F(2x2,3x3) x fp16x2 kernel (ablation bits 12..: 8 / 16)
     const int smode = variant < 0 ? 0 : ((variant & 128) ? 2 : ((variant & 64) ? 1 : 0));
-    const bool b3 = smode != 0 && !wino;
-    SG_REQUIRE(!wino || (ks == 3 && conv_wino_eligible(Cin, 0, Cout, W)), "bench_conv: shape is not eligible for the Winograd kernel");
+    const bool b3 = smode != 0 && !wino && !wino2d;
+    SG_REQUIRE(!(wino || wino2d) || (ks == 3 && conv_wino_eligible(Cin, 0, Cout, W)), "bench_conv: shape is not eligible for the Winograd kernel");
     SG_REQUIRE(!b3 || conv_split_eligible(ks, Cin, 0, Cout), "bench_conv: shape is not eligible for the split kernels");
     const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * Cout * H * W, nw = (size_t)Cout * Cin * ks * ks;
     const size_t ne = packed_weight_elems(ks, Cin, Cout, pl.co_t);
@@ -747,8 +759,8 @@ class Engine {
         }
       }
     }
-    if (wino) {
-      pk3 = pack_wino(w, Cin, Cout, false, &a.co_scale); a.w = pk3;
+    if (wino || wino2d) {
+      pk3 = wino2d ? pack_wino2d(w, Cin, Cout, false, &a.co_scale) : pack_wino(w, Cin, Cout, false, &a.co_scale); a.w = pk3;
       bounds = input_bounds(x, Cin, nullptr, 0, B, H * W);
       xbound = producer_bound(a.in_scale, a.in_shift, Cin, bounds, nullptr, B); a.xbound = xbound;
     }
@@ -760,7 +772,8 @@ class Engine {
       a.trace = trace_dev;
     }
     auto go = [&]() {
-      if (wino) launch_conv_wino(a, stream_, split_rows4, (abl_split & 64) != 0, abl_split & 63);
+      if (wino2d) launch_conv_wino2d(a, stream_, abl_split & 63);
+      else if (wino) launch_conv_wino(a, stream_, split_rows4, (abl_split & 64) != 0, abl_split & 63);
       else if (b3) launch_conv_split(a, ks, smode, stream_, split_rows4, abl_split);
       else launch_conv_mfma(a, ks, pl, stream_, variant);
     };
@@ -1004,6 +1017,20 @@ class Engine {
     DRT_LAUNCH(wino_co_scale_kernel, dim3((unsigned)((cout_pad + 255) / 256)), dim3(256), stream_, oihw, cin, cout, cout_pad, inv, sc);
     PackWinoArgs pa{oihw, pk, cin, cout, frags};
     DRT_LAUNCH(pack_weights_wino_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), stream_, pa, (const float*)sc);
+    *scale_out = inv;
+    return reinterpret_cast<const float*>(pk);
+  }
+
+  const float* pack_wino2d(const float* oihw, int cin, int cout, bool weight_owned, const float** scale_out) {
+    const size_t frags = packed_wino2d_frags(cin, cout);
+    const int cout_pad = (cout + 127) / 128 * 128;
+    const size_t bytes = packed_wino2d_bytes(cin, cout) + (size_t)cout_pad * 4;     // [fragments][inverse scales][scales (packing scratch)]
+    uint32_t* pk = static_cast<uint32_t*>(weight_owned ? dev_alloc_w(bytes) : dev_alloc_tmp(bytes));
+    float* inv = reinterpret_cast<float*>(pk) + frags * 4;
+    float* sc = inv + cout_pad;
+    DRT_LAUNCH(wino2d_co_scale_kernel, dim3((unsigned)((cout_pad + 255) / 256)), dim3(256), stream_, oihw, cin, cout, cout_pad, inv, sc);
+    PackWinoArgs pa{oihw, pk, cin, cout, frags};
+    DRT_LAUNCH(pack_weights_wino2d_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), stream_, pa, (const float*)sc);
     *scale_out = inv;
     return reinterpret_cast<const float*>(pk);
   }

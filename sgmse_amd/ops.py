@@ -45,7 +45,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     ctx.use_current_stream()
     ctx.check(ctx.lib.sgmse_op_conv2d(ctx.h, x.data_ptr(), weight.data_ptr(), _lib.ptr(_f32(bias, "bias", dev)),
                                       _lib.ptr(_f32(residual, "residual", dev)), out.data_ptr(), B, Cin, Cout, H, W, kh,
-                                      float(out_scale), {None: int(force_direct), 'bf16x3': 2, 'fp16x2': 3, 'wino': 4, 'wino4': 5, 'thin': 6}[force_split], _lib.ptr(_f32(in_scale, "in_scale", dev)),
+                                      float(out_scale), {None: int(force_direct), 'bf16x3': 2, 'fp16x2': 3, 'wino': 4, 'wino4': 5, 'thin': 6, 'wino2d': 7}[force_split], _lib.ptr(_f32(in_scale, "in_scale", dev)),
                                       _lib.ptr(_f32(in_shift, "in_shift", dev)), int(in_act),
                                       _lib.ptr(_f32(x2, "x2", dev)), C2))
     return out

@@ -122,6 +122,47 @@ def check_conv_wino(dev, B, Ci, Co, H, W, dual=0, xform=True, res=True, xmul=1.0
     assert e_w < max(slack * e_f32, 3e-7), (e_w, e_f32)
 
 
+def check_conv_wino2d(dev, B, Ci, Co, H, W, dual=0, xform=True, res=True, xmul=1.0, wmul=None, slack=2.0):
+    """The 2-D Winograd F(2x2,3x3) x fp16x2 kernel (kernels_conv_wino2d.h; round 6 -- built and measured against the 1-D kernel, not the
+    product path): the same gates as check_conv_wino -- per-op 1e-5 against the fp32 oracle and an error against an fp64 convolution within
+    `slack` x the fp32-MFMA kernel's -- and the 1-D kernel's error printed beside it."""
+    from sgmse_amd import ops
+    g = gen(B * 1000 + Ci + Co + H + W + 11)
+    x = R(g, B, Ci, H, W) * xmul; w = R(g, Co, Ci, 3, 3) / math.sqrt(Ci * 9); b = R(g, Co) * xmul
+    r = R(g, B, Co, H, W) * xmul if res else None
+    if wmul:
+        w = w * torch.logspace(-wmul / 2, wmul / 2, Co)[:, None, None, None]
+        w[1, 0, 1, 1] *= 1e6; w[Co // 2, Ci - 1, 0, 2] *= 1e4
+    if xmul != 1.0 and B > 1:
+        x[0] *= 0.01
+    sc = sh = None
+    xin = x
+    if xform:
+        sc, sh = R(g, B, Ci), R(g, B, Ci)
+        xin = x * sc[:, :, None, None] + sh[:, :, None, None]
+        xin = xin * torch.sigmoid(xin)
+    fin = lambda t: (t + (r.to(t.dtype) if res else 0)) / math.sqrt(2.0)
+    ref32 = fin(F.conv2d(xin, w, b, padding=1))
+    ref64 = fin(F.conv2d(xin.double(), w.double(), b.double(), padding=1))
+    x1, x2 = (x[:, :Ci - dual].contiguous(), x[:, Ci - dual:].contiguous()) if dual else (x, None)
+    mv = lambda t: None if t is None else t.to(dev)
+    kw = dict(residual=mv(r), out_scale=1 / math.sqrt(2.0), x2=mv(x2), in_scale=mv(sc), in_shift=mv(sh), in_act=xform)
+    out2 = ops.conv2d(mv(x1), mv(w), mv(b), force_split="wino2d", **kw).cpu()
+    out1 = ops.conv2d(mv(x1), mv(w), mv(b), force_split="wino", **kw).cpu()
+    out_f32 = ops.conv2d(mv(x1), mv(w), mv(b), **kw).cpu()
+    if wmul:
+        num = (out2.double() - ref64).pow(2).sum(dim=(0, 2, 3)).sqrt(); den = ref64.pow(2).sum(dim=(0, 2, 3)).sqrt()
+        worst = float((num / den).max())
+        print(f"conv_wino2d {Ci}->{Co} @{B}x{H}x{W} weights over {wmul} decades: worst per-channel error vs fp64 {worst:.2e}")
+        assert worst < OP_TOL, worst
+    else:
+        assert rel_l2(out2, ref32) < OP_TOL, (B, Ci, Co, H, W, dual, xform, rel_l2(out2, ref32))
+    e_2, e_1, e_f32 = rel_l2(out2.double(), ref64), rel_l2(out1.double(), ref64), rel_l2(out_f32.double(), ref64)
+    print(f"conv_wino2d {Ci}->{Co} @{B}x{H}x{W}: error vs fp64  F(2x2,3x3)-fp16x2 {e_2:.2e}  F(2,3)-fp16x2 {e_1:.2e}  fp32-MFMA {e_f32:.2e}  "
+          f"torch-fp32 {rel_l2(ref32.double(), ref64):.2e}")
+    assert e_2 < max(slack * e_f32, 3e-7), (e_2, e_f32)
+
+
 def check_conv_thin_batch_independence(dev):
     """The VALU kernel of the pyramid convolutions gives an utterance the same bits alone and inside a batch (its accumulation order is a
     function of the layer only), with and without the residual / producer, at widths that leave partial 16 x 64 tiles."""

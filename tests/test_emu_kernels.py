@@ -73,6 +73,15 @@ def test_conv3x3_winograd_fp16x2_kernel_has_fp32_accuracy(emu):
     P.check_conv_wino(emu, 1, 32, 128, 8, 32, wmul=6)
 
 
+def test_conv3x3_winograd_2d_fp16x2_kernel_has_fp32_accuracy(emu):
+    """kernels_conv_wino2d.h (round 6: F(2x2,3x3) x fp16x2, measured against the 1-D kernel and not taken): the same accuracy gates."""
+    P.check_conv_wino2d(emu, 1, 32, 128, 9, 34)
+    P.check_conv_wino2d(emu, 2, 48, 128, 8, 32, xmul=50.0)
+    P.check_conv_wino2d(emu, 1, 64, 256, 6, 40, dual=32)
+    P.check_conv_wino2d(emu, 1, 16, 128, 12, 64, xform=False, res=False)
+    P.check_conv_wino2d(emu, 1, 32, 128, 8, 32, wmul=6)
+
+
 def test_conv3x3_thin_output_valu_kernel(emu):
     """C -> 4 pyramid convolutions on the exact-fp32 VALU kernel (kernels_conv_thin.h; the engine's path for these layers): fp32
     accuracy against float64 (no worse than 1.5x the fp32 MFMA kernel's own error), ragged tile edges, 2 output channels, dual input."""

@@ -14,6 +14,8 @@ from oracle import stft_oracle as FO
 from oracle import synth
 
 pytestmark = pytest.mark.gpu
+FULL = bool(os.environ.get("SGMSE_TEST_FULL"))
+full_only = pytest.mark.skipif(not FULL, reason="second copy of a covered row; set SGMSE_TEST_FULL=1")
 
 
 @pytest.mark.parametrize("shape", [
@@ -70,6 +72,18 @@ def test_conv3x3_winograd_fp16x2_kernel_has_fp32_accuracy(hip):
     P.check_conv_wino(hip, 1, 384, 128, 32, 64, dual=128)
     P.check_conv_wino(hip, 1, 512, 256, 16, 32, dual=256)
     P.check_conv_wino(hip, 2, 256, 256, 64, 128, wmul=4)
+
+
+def test_conv3x3_winograd_2d_fp16x2_kernel_has_fp32_accuracy(hip):
+    """kernels_conv_wino2d.h (round 6: F(2x2,3x3) x fp16x2, measured against the 1-D kernel and not taken): the same accuracy gates."""
+    P.check_conv_wino2d(hip, 1, 32, 128, 9, 34)
+    P.check_conv_wino2d(hip, 2, 48, 128, 8, 32, xmul=50.0)
+    P.check_conv_wino2d(hip, 1, 64, 256, 6, 40, dual=32)
+    P.check_conv_wino2d(hip, 1, 16, 128, 12, 64, xform=False, res=False)
+    P.check_conv_wino2d(hip, 1, 32, 128, 8, 32, wmul=6)
+    P.check_conv_wino2d(hip, 2, 128, 128, 64, 96)
+    P.check_conv_wino2d(hip, 1, 384, 128, 32, 64, dual=128)
+    P.check_conv_wino2d(hip, 2, 256, 256, 64, 128, wmul=4)
 
 
 def test_conv3x3_bf16x3_kernel_has_fp32_accuracy(hip):
@@ -356,8 +370,6 @@ def test_full_width_48k_forward_at_the_benched_shape_against_oracle(hip):
 # Round 6 (the GPU suite under 8 minutes with the same row coverage): second copies of what a full-configuration
 # fixture already covers run under SGMSE_TEST_FULL=1 only -- pc48k_full (T = 128) and pc48k_T512 (N = 5) beside pc48k_T512_N50 (the
 # benched shape at the full N = 50); the 722-evaluation adaptive-ODE fixture beside the 1e-3 one; the two-process rehearsal.
-FULL = bool(os.environ.get("SGMSE_TEST_FULL"))
-full_only = pytest.mark.skipif(not FULL, reason="second copy of a covered row; set SGMSE_TEST_FULL=1")
 
 
 @pytest.mark.parametrize("name", ["pc16k_full", "ode16k_full", pytest.param("pc48k_full", marks=full_only),
@@ -373,7 +385,10 @@ def test_batch_of_four_equals_four_singles_bitwise(hip):
     P.check_batch_equals_singles(hip, 4)
 
 
-@pytest.mark.parametrize("kind", ["gn_inside", "gn_outside", "gn_wild", "growth", "outliers", "single_weights", "zero_init"])
+# (round 6, suite time: three of the seven adversarial state dicts by default -- the widest GroupNorm case, the outlier channels and the
+#  dead branches; the milder variants of the same mechanisms under SGMSE_TEST_FULL=1.  18 s each, most of it the CPU oracle.)
+@pytest.mark.parametrize("kind", [pytest.param("gn_inside", marks=full_only), pytest.param("gn_outside", marks=full_only), "gn_wild",
+                                  pytest.param("growth", marks=full_only), "outliers", pytest.param("single_weights", marks=full_only), "zero_init"])
 def test_adversarial_checkpoints_keep_the_network_gate(hip, kind):
     """Full-width network at the bench shape (T = 512) with synthetic state dicts built to stress the fp16x2 range handling
     (GroupNorm parameters far beyond any worst-case guard, a residual stream growing 10^3, outlier channels x 10^4, single weights x 10^6, dead Conv_1
@@ -404,6 +419,7 @@ def test_long_utterance_keeps_the_fp16x2_kernels(hip, capfd):
     assert torch.equal(net(short.to(hip), torch.tensor([0.5], device=hip)).cpu(), o_short)
 
 
+@full_only      # (66 s; the length axis stays covered by test_long_utterance_keeps_the_fp16x2_kernels, the GroupNorm axis by gn_wild above)
 def test_full_width_60_s_utterance_with_gamma_8_stays_on_the_fast_kernels(hip):
     """the full-width network, GroupNorm gamma up to 8 (single channels 30, beta up to 500), one 60 s utterance
     (T = 7552 frames: groups of 2^24 elements) -- mode 2, network gate against the oracle."""

@@ -34,6 +34,8 @@ def sample(stop, out):
 CASES = {"split": ("fp16x2 split kernel (full)", 128), "mfma_only": ("fp16x2 MFMA-only loop, no epilogue memory (ablation 59)", 128 + (59 << 12)),
          "no_staging": ("fp16x2 no staging (ablation 8)", 128 + (8 << 12)), "fp32": ("fp32 MFMA kernel", 0),
          "wino": ("Winograd F(2,3) x fp16x2 kernel", 128 + 1024),
+         "wino2d": ("2-D Winograd F(2x2,3x3) x fp16x2 kernel", 128 + 2048),
+         "wino2d_mfma_only": ("2-D Winograd kernel without staging behind the prologue (ablation 8)", 128 + 2048 + (8 << 12)),
          "wino_mfma_only": ("Winograd kernel without staging and raw loads behind the prologue (ablation 24; ABLATION=1 build)", 128 + 1024 + (24 << 12))}
 ITERS = int(os.environ.get("ITERS", "3500"))
 
