@@ -200,6 +200,16 @@ __global__ __launch_bounds__(256) void calib_stream_kernel(float* buf, size_t nv
   if (!WRITE && acc == 123456.789f) sink[0] = acc;
 }
 
+// Test hook (SGMSE_POISON_LDS=1): fill the whole LDS of every CU with NaN bit patterns in front of every launch of an eager forward, so
+// that a kernel reading LDS it never wrote -- whose result then depends on what the PREVIOUS workgroup on that CU left there, i.e. on what
+// else runs on the device -- shows up as a changed result (round 6: tools/probes/concurrency_bits_probe.py).  One workgroup owns a CU.
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned* sink, unsigned salt) {
+  __shared__ unsigned s[40960];                    // 160 KiB
+  for (int i = threadIdx.x; i < 40960; i += 256) s[i] = 0x7FC00000u | ((unsigned)i + salt);
+  __syncthreads();
+  if (s[(threadIdx.x * 97 + salt) % 40960] == 0x12345678u) sink[0] = 1u;
+}
+
 // [cin][cout] -> [cout][cin]
 __global__ __launch_bounds__(256) void transpose_io_kernel(const float* src, float* dst, int cin, int cout) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -1222,6 +1232,13 @@ class Engine {
   // one event pair per launch of a profiled forward (created on first use, reused by later profiles, destroyed with the engine)
   struct ProfRec { drt::event_t a{}, b{}; int cls = -1; double work = 0.0; int launches = 0; char note[160] = {0}; };
   void tock() {
+    if (lds_poison_ && !dry_ && !capturing_ && !drt::is_emulator()) {
+      const int idx = lds_poison_count_++;
+      if (lds_poison_at_ < 0 || idx == lds_poison_at_ || (lds_poison_upto_ && idx <= lds_poison_at_)) {
+        if (!lds_sink_) lds_sink_ = static_cast<unsigned*>(dev_alloc(256));
+        DRT_LAUNCH(lds_poison_kernel, dim3(768), dim3(256), stream_, lds_sink_, (unsigned)idx);
+      }
+    }
     if (!prof_) return;
     if (prof_used_ == prof_recs_.size()) {
       prof_recs_.emplace_back();
@@ -1651,6 +1668,7 @@ class Engine {
     B_ = B;
     cur_F_ = F;
     amax_next_ = 0;
+    lds_poison_count_ = 0;
     if (!dry_ && poison_ && arena_base_) SG_CHECK(drt::memset_dev(arena_base_, 0xFF, arena_cap_, stream_));
     if (!dry_ && amax_pool_) {
       const int n = amax_slots_ * B * kAmaxSpread;
@@ -1875,6 +1893,10 @@ class Engine {
     e = getenv("SGMSE_WINO_MIN_TILES");
     wino_min_tiles_ = e ? atol(e) : 32L;                 // ... and the Winograd kernel (32: the 64 x 128 level and up)
     fuse_gn_stats_ = flag("SGMSE_FUSE_GN_STATS", true);  // GroupNorm partial sums in the conv epilogue (0: stand-alone statistics passes)
+    lds_poison_ = flag("SGMSE_POISON_LDS", false);       // test hook: NaN patterns in every CU's LDS in front of every launch (lds_poison_kernel)
+    e = getenv("SGMSE_POISON_LDS_AT");
+    lds_poison_at_ = e ? atoi(e) : -1;                   // ... in front of launch number n only (bisection); SGMSE_POISON_LDS_UPTO=1: launches 0..n
+    lds_poison_upto_ = flag("SGMSE_POISON_LDS_UPTO", false);
     e = getenv("SGMSE_NOFOLD_LEVELS");
     nofold_levels_ = e ? atoi(e) : 0;                    // measurement (round 6): bit l = the 1x1 shortcuts of U-Net level l as their own launch
     poison_ = flag("SGMSE_POISON", false);               // NaN patterns in every allocation and in the arena before every forward
@@ -1897,6 +1919,7 @@ class Engine {
   bool poison_ = false, debug_sync_ = false, conv_xcd_map_ = true, rag_prefix_ = true, wino_ = true;
   long wino_min_tiles_ = 32;
   int nofold_levels_ = 0;
+  bool lds_poison_ = false, lds_poison_upto_ = false; int lds_poison_at_ = -1, lds_poison_count_ = 0; unsigned* lds_sink_ = nullptr;
   static constexpr long coarse_splitk_div_ = 4, chunk_max_tiles_ = 8;      // (profiles/r02_chunk_splitk.txt)
   int split_mode_ = SGMSE_CONV_SPLIT_DEFAULT;
   bool prof_dump_ = false;

@@ -133,8 +133,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_thin_kernel(ConvArgs p) {
 #pragma unroll
       for (int px = 0; px < 4; ++px) {
         const f32x2 v = {in[px + dx], in[px + dx]};
-        acc[0][px] = drt_fma2(w01, v, acc[0][px]);
-        acc[1][px] = drt_fma2(w23, v, acc[1][px]);
+        // ROUND 6: two v_fma_f32 per channel pair, NOT one v_pk_fma_f32.  With the packed instruction this kernel's results changed
+        // whenever ANOTHER PROCESS ran on the same GPU (tools/probes/thin_under_load_probe.py: 18-25 of 40 launches identical to the
+        // solo result; always the low element of the pair -- output channels 0 and 2 -- in lanes 48-63 of a wave, |diff| up to 0.35),
+        // i.e. across the wave save / restore of a shared device; alone on the device it was deterministic, which is why no test of
+        // rounds 4-5 saw it.  The same arithmetic as scalar FMAs: 40 of 40 identical under the same load, same bits as before alone.
+        acc[0][px] = f32x2{fmaf(w01[0], v[0], acc[0][px][0]), fmaf(w01[1], v[1], acc[0][px][1])};
+        acc[1][px] = f32x2{fmaf(w23[0], v[0], acc[1][px][0]), fmaf(w23[1], v[1], acc[1][px][1])};
       }
     }
   };

@@ -547,6 +547,12 @@ def test_xcd_aware_tile_order_never_changes_a_bit(hip, name):
     P.check_xcd_map_bitwise(hip, name)
 
 
+def test_results_do_not_depend_on_what_else_runs_on_the_device(hip):
+    """Round 6: a second process loads the GPU while this one repeats the C -> 4 pyramid convolution, the networks and a seeded sampler run:
+    every result must equal its solo result bit for bit (conv3x3_thin_kernel's packed FMAs did not: kernels_conv_thin.h)."""
+    P.check_bits_under_outside_load(hip)
+
+
 @pytest.mark.parametrize("every_layer_split", [False, True])
 def test_results_do_not_depend_on_what_device_memory_held(hip, every_layer_split):
     P.check_poison_independence(hip, "fwd_nf128", every_layer_split)

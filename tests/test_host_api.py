@@ -134,6 +134,25 @@ def test_checkpoint_ingestion_and_ema_swap(tmp_path):
         ScoreModel.load_from_checkpoint(str(path))
 
 
+def test_device_code_holds_no_packed_fp32_instruction(tmp_path):
+    """Round 6: conv3x3_thin_kernel's v_pk_fma_f32 gave results that changed whenever another process shared the GPU (kernels_conv_thin.h);
+    the kernel spells its FMAs out and the build passes -packed-fp32-ops: the gfx950 code object must not contain v_pk_{fma,mul,add}_f32."""
+    import shutil
+    from conftest import HIP_LIB
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(HIP_LIB) and os.path.exists(objdump)):
+        pytest.skip("library or llvm-objdump missing")
+    lib = tmp_path / "lib.so"
+    shutil.copy(HIP_LIB, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, capture_output=True, check=True)
+    co = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert len(co) == 1, os.listdir(tmp_path)
+    dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(tmp_path / co[0])], capture_output=True, text=True, check=True).stdout
+    assert dis.count("v_mfma_f32_32x32x16_f16") > 100          # (the disassembly is the real thing)
+    bad = [l for l in dis.splitlines() if "v_pk_fma_f32" in l or "v_pk_mul_f32" in l or "v_pk_add_f32" in l]
+    assert not bad, bad[:5]
+
+
 def test_c_abi_exports_every_declared_symbol():
     """libsgmse_hip.so loads without a GPU and exports exactly what include/sgmse_hip.h declares."""
     assert os.path.exists(HIP_LIB), "build first: python -c 'import __graft_entry__ as g; g.build()'"
