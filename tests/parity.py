@@ -938,6 +938,8 @@ def check_bits_under_outside_load(dev, seconds=30):
     m, _ = make_model(NET_CASES["fwd_nf32"], dev)
     y = synth.synth_spec(2, 256, 64, seed=3).to(dev)
     cases["pc sampler N = 3 (captured graph, in-kernel noise, seed 5)"] = (lambda: m.get_pc_sampler("reverse_diffusion", "ald", y, N=3, snr=0.5, seed=5)()[0], 10)
+    wav = synth.synth_waveform(8000, seed=1, batch=2).to(dev)
+    cases["enhance_batch: STFT -> PC sampler N = 2 -> iSTFT (seed 9)"] = (lambda: torch.as_tensor(m.enhance_batch(wav, N=2, snr=0.5, seed=9)[0]), 10)
     ref = {k: f().cpu() for k, (f, _) in cases.items()}
     for k, (f, _) in cases.items():
         assert torch.equal(f().cpu(), ref[k]), k + ": not reproducible even alone"
