@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <stdexcept>
 
+#include <deque>
 #include <sgmse_devrt.h>
 #include "kernels_conv.h"
 #include "conv_launch.h"
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void transpose_io_kernel(const float* src, flo
 // the high-water mark is tracked (used to size the real arena before the first run / graph capture).
 class Arena {
  public:
-  void reset() { free_.clear(); free_.push_back({0, cap_}); live_.clear(); }
+  void reset() { free_.clear(); free_.push_back({0, cap_}); live_.clear(); deferring_ = false; deferred_.clear(); }
   void configure(char* base, size_t cap) { base_ = base; cap_ = cap; live_.clear(); reset(); }
   // measure mode hands out addresses from an unmapped fake range; they are never dereferenced (dry run)
   void measure_mode() { base_ = reinterpret_cast<char*>(uintptr_t(1) << 44); cap_ = size_t(1) << 42; high_ = 0; reset(); live_.clear(); }
@@ -243,8 +244,14 @@ class Arena {
     }
     throw EngineError("activation arena exhausted");
   }
+  // Deferred releases (side branches of the forward on a second stream, Engine::side_begin): a buffer released by the side branch, or
+  // by the main chain while the side branch may still read it, goes back to the pool only at the join -- nothing enqueued in between
+  // can be handed memory that an unfinished kernel of the other stream still uses.
+  void defer_begin() { deferring_ = true; }
+  void defer_end() { deferring_ = false; std::vector<float*> d; d.swap(deferred_); for (float* p : d) release(p); }
   void release(float* p) {
     if (!p) return;
+    if (deferring_) { deferred_.push_back(p); return; }
     const size_t off = size_t(reinterpret_cast<char*>(p) - base_);
     auto it = live_.find(off);
     SG_REQUIRE(it != live_.end(), "arena: bad release");
@@ -265,6 +272,8 @@ class Arena {
   size_t cap_ = 0, high_ = 0;
   std::vector<std::pair<size_t, size_t>> free_;
   std::map<size_t, size_t> live_;
+  bool deferring_ = false;
+  std::vector<float*> deferred_;
 };
 
 // st: [B][C][nsub][2] GroupNorm partial sums; amax: [B] upper bounds of |x| per utterance (null: unknown range)
@@ -320,6 +329,8 @@ class Engine {
     if (graph_valid_ || graph_stale_) drt::graph_destroy(&graph_);
     if (hstage_) drt::free_host(hstage_);
     if (hstage_ev_init_) drt::event_destroy(&hstage_ev_);
+    for (drt::event_t& e : side_ev_) drt::event_destroy(&e);
+    if (side_stream_ready_) drt::stream_destroy(side_stream_);
     for (ProfRec& r : prof_recs_) { drt::event_destroy(&r.a); drt::event_destroy(&r.b); }
   }
 
@@ -1597,13 +1608,28 @@ class Engine {
     const float* temb = ctl.bias_table ? ctl.bias_table + r.temb_off : nullptr;
     Tensor h, xs;       // xs: resampled shortcut input (only for up/down)
     bool have_xs = false;
+    // The block's 1x1 shortcut Conv_2 (layerspp.py:266-269), where it is its own launch (not folded into Conv_1's launch: the levels
+    // below the split kernels' threshold, and any layer the fold's conditions exclude): it needs the block input only and its result only
+    // at the end of the block, so at small batches it runs on the side stream beside GroupNorm - Conv_0 - GroupNorm (round 6).
+    Tensor sh_t; bool sc_side = false;
+    auto shortcut_early = [&](const Tensor& sa, const Tensor* sb, int Ch, int Hh) {
+      if (!r.has_c2) return;
+      const bool fold = runs_on_h2_split3(r.c1, Ch, Hh, dec_W(Hh)) && shortcut_foldable(r.c2, sa, sb) && !((nofold_levels_ >> level_of(Hh)) & 1);
+      if (fold || !side_enabled()) return;
+      side_begin();
+      sh_t = conv(r.c2, sa, sb, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl);
+      side_end();
+      sc_side = true;
+    };
     if (m.up || m.down) {
       SG_REQUIRE(b == nullptr, "resample block with concat input");
       Tensor hr = fir(a, m.up, x0, &xs);
       have_xs = true;
+      shortcut_early(xs, nullptr, r.c0.cout, hr.H);
       h = conv(r.c0, hr, nullptr, Xform{nullptr, nullptr, 0, bd0}, nullptr, temb, nullptr, 1.f, ctl, true);
       drop(hr);
     } else {
+      shortcut_early(a, b, r.c0.cout, a.H);
       h = conv(r.c0, a, b, x0, nullptr, temb, nullptr, 1.f, ctl, true);
     }
     arena_.release(sc0); arena_.release(sh0);
@@ -1619,7 +1645,8 @@ class Engine {
         const Shortcut scin{&r.c2, &sa, sb};
         out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, nullptr, inv_sqrt2, ctl, true, &scin);
       } else {
-        Tensor sh_t = conv(r.c2, sa, sb, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl);
+        if (sc_side) side_join();                    // (also joins a pyramid branch still pending from the level above)
+        else sh_t = conv(r.c2, sa, sb, Xform{}, r.c2.bias, nullptr, nullptr, 1.f, ctl);
         out = conv(r.c1, h, nullptr, x1, r.c1.bias, nullptr, sh_t.p, inv_sqrt2, ctl, true);
         drop(sh_t);
       }
@@ -1654,9 +1681,72 @@ class Engine {
     return out;
   }
 
+  // ---- side stream (round 6) ---------------------------------------------------------------------------------------------------------
+  // Launches that the main chain needs only later -- the output-pyramid branch of a level (run_forward), the 1x1 shortcut of a residual
+  // block that is not folded into the block's second 3x3 launch (res_block) -- go to the engine's SECOND STREAM at small batches, where
+  // they are latency, not throughput:
+  //   side_begin() .. side_end(): the launches in between run on the side stream, ordered behind everything the main stream holds at
+  //     side_begin() (an event recorded there); sections may follow each other before a join (the side stream keeps their order);
+  //   side_join(): the main stream waits for everything the side stream holds.
+  // From the first side_begin() to the join every arena release is DEFERRED (Arena::defer_begin): memory freed on one stream's behalf is
+  // not handed to the other stream's later launches while its last user may still run -- in the dry run too, so that the planned arena
+  // is the one the real run uses.  Same kernels, same arguments, same bits (test_sampler_graph_equals_eager, the batch-independence and
+  // device-memory tests, tools/probes/side_stream_bits_probe.py).  Off above side_max_batch_ utterances (no deferral either: the arena of
+  // the large batches is unchanged) and for instrumented evaluations (one stream: profile_forward times launches that follow each other).
+  bool side_enabled() const { return side_stream_on_ && B_ <= side_max_batch_; }
+  bool side_active() const { return side_enabled() && !prof_ && !dry_ && !drt::is_emulator(); }
+  drt::event_t* side_event() {
+    if (side_ev_next_ == side_ev_.size()) { side_ev_.emplace_back(); SG_CHECK(drt::event_create_order(&side_ev_.back())); }
+    return &side_ev_[side_ev_next_++];
+  }
+  void side_begin() {
+    SG_REQUIRE(!side_open_, "side stream: nested section");
+    side_open_ = true;
+    if (!side_enabled()) return;
+    if (!side_pending_) arena_.defer_begin();
+    if (!side_active()) return;
+    if (!side_stream_ready_) { SG_CHECK(drt::stream_create(&side_stream_)); side_stream_ready_ = true; }
+    drt::event_t* e = side_event();
+    SG_CHECK(drt::event_record(e, stream_));
+    SG_CHECK(drt::stream_wait_event(side_stream_, e));
+    std::swap(stream_, side_stream_);
+    side_swapped_ = true;
+  }
+  void side_end() {
+    SG_REQUIRE(side_open_, "side stream: end without begin");
+    side_open_ = false;
+    if (!side_enabled()) return;
+    side_pending_ = true;
+    if (!side_swapped_) return;
+    drt::event_t* e = side_event();
+    SG_CHECK(drt::event_record(e, stream_));         // (stream_ is the side stream here)
+    std::swap(stream_, side_stream_);
+    side_swapped_ = false;
+    side_join_ev_ = e;                               // (the side stream is in order: its latest event covers the earlier sections)
+  }
+  void side_join() {
+    if (!side_pending_) return;
+    side_pending_ = false;
+    if (side_join_ev_) { SG_CHECK(drt::stream_wait_event(stream_, side_join_ev_)); side_join_ev_ = nullptr; }
+    arena_.defer_end();
+  }
+  drt::stream_t side_stream_{}; bool side_stream_ready_ = false, side_open_ = false, side_pending_ = false, side_swapped_ = false;
+  std::deque<drt::event_t> side_ev_; size_t side_ev_next_ = 0; drt::event_t* side_join_ev_ = nullptr;
+  bool side_stream_on_ = true; int side_max_batch_ = 8;
+
   // NCSNpp.forward (ncsnpp.py:256-419) / NCSNpp_48k.forward
   void run_forward(const float2* x, long long xbs, const float2* y, long long ybs, float2* out, int B, int F, int T,
                    const FwdCtl& ctl_in) {
+    side_ev_next_ = 0; side_open_ = side_pending_ = false; side_join_ev_ = nullptr;
+    try { run_forward_main(x, xbs, y, ybs, out, B, F, T, ctl_in); }
+    catch (...) {                 // never leave the engine on its side stream
+      if (side_swapped_) { std::swap(stream_, side_stream_); side_swapped_ = false; }
+      side_open_ = side_pending_ = false; side_join_ev_ = nullptr;
+      throw;
+    }
+  }
+  void run_forward_main(const float2* x, long long xbs, const float2* y, long long ybs, float2* out, int B, int F, int T,
+                        const FwdCtl& ctl_in) {
     FwdCtl ctl = ctl_in;
     ctl.bias_step = ctl.step_ptr;
     if (!dry_ && ctl.step_ptr && ctl.bias_table && ctl.bias_bstride == 0 && tot_temb_ > 0) {
@@ -1754,7 +1844,12 @@ class Engine {
         drop(h); h = h2;
       }
       if (c.progressive == 1) {
+        // The output-pyramid branch of the level (GroupNorm finalize, C -> 4 convolution, 4-channel FIR; ncsnpp.py:358-379) reads h and the
+        // previous level's pyramid only and rejoins the main chain at the network's exit: it runs on the engine's SIDE STREAM beside the
+        // level's up-sampling block (round 6; small batches, where these launches are latency, not throughput).  Same kernels, same
+        // arguments, same bits; the join sits in front of drop(h).
         const Mod& mg = next(); const Mod& mc = next();
+        side_begin();
         float *sc, *sh;
         const float* bd;
         gn_coeffs(h, nullptr, gn_.at(mg.idx).first, gn_.at(mg.idx).second, &sc, &sh, &bd);
@@ -1765,13 +1860,16 @@ class Engine {
         have_pyr = true;
         if (have_up) drop(up);
         arena_.release(sc); arena_.release(sh);
+        side_end();
       }
       if (l != 0) {
         const Mod& m = next();
         Tensor o = res_block(m, h, nullptr, ctl);
+        side_join();
         drop(h); h = o;
       }
     }
+    side_join();
     SG_REQUIRE(hs.empty(), "skip stack not empty");
     Tensor h4;
     if (c.progressive == 1) { h4 = pyramid; drop(h); }
@@ -1897,6 +1995,9 @@ class Engine {
     e = getenv("SGMSE_POISON_LDS_AT");
     lds_poison_at_ = e ? atoi(e) : -1;                   // ... in front of launch number n only (bisection); SGMSE_POISON_LDS_UPTO=1: launches 0..n
     lds_poison_upto_ = flag("SGMSE_POISON_LDS_UPTO", false);
+    side_stream_on_ = flag("SGMSE_SIDE_STREAM", true);   // output-pyramid branches on the second stream (run_forward) ...
+    e = getenv("SGMSE_SIDE_MAX_BATCH");
+    side_max_batch_ = e ? atoi(e) : 8;                   // ... for batches up to this size (batch 1: -1.4 %, batch 4 / 8: -0.8 %; nothing at 32: profiles/r06_side_stream.txt)
     e = getenv("SGMSE_NOFOLD_LEVELS");
     nofold_levels_ = e ? atoi(e) : 0;                    // measurement (round 6): bit l = the 1x1 shortcuts of U-Net level l as their own launch
     poison_ = flag("SGMSE_POISON", false);               // NaN patterns in every allocation and in the arena before every forward

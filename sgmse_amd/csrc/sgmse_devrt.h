@@ -160,6 +160,11 @@ inline int memcpy_d2h(void* d, const void* s, size_t n, stream_t st) { return in
 inline int memcpy_d2d(void* d, const void* s, size_t n, stream_t st) { return int(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st)); }
 inline int memset_dev(void* d, int v, size_t n, stream_t st) { return int(hipMemsetAsync(d, v, n, st)); }
 inline int stream_sync(stream_t st) { return int(hipStreamSynchronize(st)); }
+// a second stream of the engine (side branches of the captured step) and the ordering events between the two (no timing)
+inline int stream_create(stream_t* st) { return int(hipStreamCreateWithFlags(st, hipStreamNonBlocking)); }
+inline int stream_destroy(stream_t st) { return int(hipStreamDestroy(st)); }
+inline int event_create_order(event_t* e) { return int(hipEventCreateWithFlags(&e->e, hipEventDisableTiming)); }
+inline int stream_wait_event(stream_t st, event_t* e) { return int(hipStreamWaitEvent(st, e->e, 0)); }
 inline int last_error() { return int(hipGetLastError()); }
 inline const char* error_string(int e) { return hipGetErrorString(hipError_t(e)); }
 inline int event_create(event_t* e) { return int(hipEventCreate(&e->e)); }

@@ -169,6 +169,10 @@ inline int memcpy_d2h(void* d, const void* s, size_t n, stream_t) { memcpy(d, s,
 inline int memcpy_d2d(void* d, const void* s, size_t n, stream_t) { memmove(d, s, n); return 0; }
 inline int memset_dev(void* d, int v, size_t n, stream_t) { memset(d, v, n); return 0; }
 inline int stream_sync(stream_t) { return 0; }
+inline int stream_create(stream_t* st) { *st = nullptr; return 0; }      // (launches are synchronous: a second stream orders nothing)
+inline int stream_destroy(stream_t) { return 0; }
+inline int event_create_order(struct event_t*) { return 0; }
+inline int stream_wait_event(stream_t, struct event_t*) { return 0; }
 inline int last_error() { return 0; }
 inline const char* error_string(int) { return "emulator"; }
 double wall_ms();

@@ -382,26 +382,27 @@ def check_split_workgroup_shapes_bitwise(dev, name="fwd_nf128"):
     assert rel_l2(outs[0], torch.from_numpy(z["out"])) < NET_TOL
 
 
-def check_xcd_map_bitwise(dev, name="fwd_nf32", batch=None):
+def check_xcd_map_bitwise(dev, name="fwd_nf32", batch=None, knob="SGMSE_CONV_XCD_MAP"):
     """SGMSE_CONV_XCD_MAP=1 only permutes which workgroup computes which tile (XCD k takes the k-th contiguous eighth of a launch's
-    tiles): the network's output must not change by a bit."""
+    tiles); SGMSE_SIDE_STREAM=1 (round 6) moves the pyramid branches and the unfolded shortcuts to a second stream (and defers arena
+    releases across the fork): the network's output must not change by a bit."""
     cfg = NET_CASES[name]
     z = load(name)
     x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
     if batch is not None:
         x, t = x[:batch], t[:batch]
-    old = os.environ.get("SGMSE_CONV_XCD_MAP")
+    old = os.environ.get(knob)
     outs = []
     try:
         for m in ("0", "1"):
-            os.environ["SGMSE_CONV_XCD_MAP"] = m
+            os.environ[knob] = m
             net, _ = make_backbone(cfg, dev)
             outs.append(net(x.to(dev), t.to(dev)).cpu())
     finally:
         if old is None:
-            os.environ.pop("SGMSE_CONV_XCD_MAP", None)
+            os.environ.pop(knob, None)
         else:
-            os.environ["SGMSE_CONV_XCD_MAP"] = old
+            os.environ[knob] = old
     assert torch.equal(outs[0], outs[1])
     assert rel_l2(outs[0], torch.from_numpy(z["out"])[:len(x)]) < NET_TOL
 

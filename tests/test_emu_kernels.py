@@ -179,6 +179,7 @@ def test_conv_tile_shape_never_changes_a_bit(emu):
 
 def test_xcd_aware_tile_order_never_changes_a_bit(emu):
     P.check_xcd_map_bitwise(emu, "fwd_nf32", batch=1)
+    P.check_xcd_map_bitwise(emu, "fwd_nf32", batch=1, knob="SGMSE_SIDE_STREAM")     # (round 6; on the emulator: the deferred arena releases and the early shortcut launch)
 
 
 def test_weight_reload(emu):

@@ -547,6 +547,14 @@ def test_xcd_aware_tile_order_never_changes_a_bit(hip, name):
     P.check_xcd_map_bitwise(hip, name)
 
 
+@pytest.mark.parametrize("name", ["fwd_nf32", "fwd_nf128"])
+def test_side_stream_never_changes_a_bit(hip, name):
+    """SGMSE_SIDE_STREAM (round 6, on for batches up to 8): the output-pyramid branches and the unfolded 1x1 shortcuts run on the engine's second
+    stream, arena releases are deferred across the fork: same kernels, same arguments -- the same bits as the one-stream forward, run after run."""
+    for _ in range(3):
+        P.check_xcd_map_bitwise(hip, name, knob="SGMSE_SIDE_STREAM")
+
+
 def test_results_do_not_depend_on_what_else_runs_on_the_device(hip):
     """Round 6: a second process loads the GPU while this one repeats the C -> 4 pyramid convolution, the networks and a seeded sampler run:
     every result must equal its solo result bit for bit (conv3x3_thin_kernel's packed FMAs did not: kernels_conv_thin.h)."""
