@@ -35,7 +35,8 @@ if "--load" in sys.argv:
 
 net = model()
 g = torch.Generator().manual_seed(3)
-cases = {T: ((torch.randn(1, 2, 256, T, dtype=torch.complex64, generator=g) * 0.3).cuda(), torch.tensor([0.4]).cuda()) for T in [int(v) for v in os.environ.get("PROBE_T", "64,512").split(",")]}
+PB = int(os.environ.get("PROBE_B", "1"))
+cases = {T: ((torch.randn(PB, 2, 256, T, dtype=torch.complex64, generator=g) * 0.3).cuda(), torch.full((PB,), 0.4).cuda()) for T in [int(v) for v in os.environ.get("PROBE_T", "64,512").split(",")]}
 ref = {T: net(x, t).cpu() for T, (x, t) in cases.items()}
 solo = {T: all(torch.equal(net(x, t).cpu(), ref[T]) for _ in range(5)) for T, (x, t) in cases.items()}
 print("alone on the device: repeated forwards identical:", solo, flush=True)

@@ -52,6 +52,19 @@ cases["attention C=256 S=64"] = lambda: ops.attention(qkv)
 qkv2 = R(1, 768, 512)
 cases["attention C=256 S=512"] = lambda: ops.attention(qkv2)
 
+if "--as-load" in sys.argv:
+    # run ONE op in a loop (the aggressor side of tools/probes/pk_fma_probe.hip): which kernel disturbs packed FMAs of another process?
+    name = sys.argv[sys.argv.index("--as-load") + 1]
+    f = cases[name]
+    t0 = time.time()
+    while time.time() - t0 < float(os.environ.get("LOAD_SECONDS", "8")):
+        for _ in range(50):
+            f()
+        torch.cuda.synchronize()
+    sys.exit(0)
+if "--list" in sys.argv:
+    print("\n".join(cases))
+    sys.exit(0)
 ref = {k: f().cpu() for k, f in cases.items()}
 for k, f in cases.items():
     assert torch.equal(f().cpu(), ref[k]), k + " is not reproducible even alone"
