@@ -339,6 +339,7 @@ def test_full_size_forward_against_oracle(hip):
     assert rel_l2(out.cpu(), ref) < P.NET_TOL
 
 
+@full_only      # (17 s; the same network at the benched shape, F = 768 x T = 512, runs by default right below)
 def test_full_width_48k_forward_against_oracle(hip):
     """ncsnpp_48k at full width (F = 768, no pyramids, bottleneck attention only) with the split kernels on its wide
     levels, against the CPU oracle."""
