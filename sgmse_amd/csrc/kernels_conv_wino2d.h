@@ -27,7 +27,7 @@
 //     row transform through two whole-wave DPP shifts, fp32 result to a scratch tile [row][tile column][hc][channel]; phase 2 -- a lane
 //     owns (position, hc, 4 channels): four scratch rows -> column transform -> split -> 8-byte stores into the B tile.  Pipelined over
 //     the stages (phase 1 of stage s + 2 and phase 2 of stage s + 1 beside the MFMAs of stage s), one barrier per stage;
-//   * A operand: [co block][stage][component 16][split][cf][lane] 16-byte fragments from global memory (L2), ring of three;
+//   * A operand: [co block][stage][component 16][split][cf][lane] 16-byte fragments from global memory (L2), ring of four (three components ahead);
 //   * epilogue: column transform in registers, partner waves (kh = 0 / 1) swap half of their row-transform terms through LDS; the
 //     A-wave ends with the even rows of the tile, the B-wave with the odd rows (a lane holds a column pair: 8-byte stores).
 #pragma once
