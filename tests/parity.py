@@ -944,19 +944,33 @@ def check_bits_under_outside_load(dev, seconds=26):
     ref = {k: f().cpu() for k, (f, _) in cases.items()}
     for k, (f, _) in cases.items():
         assert torch.equal(f().cpu(), ref[k]), k + ": not reproducible even alone"
+    # the load process announces itself once its first forward has run (a cold box can take a minute to import torch) and is ended by this
+    # test, not by its own clock: the checks below always run beside it
+    import tempfile
+    stop_file = os.path.join(tempfile.mkdtemp(prefix="sgmse_load_"), "stop")
     load = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "probes", "concurrency_bits_probe.py"), "--load"],
-                            env=dict({kk: vv for kk, vv in os.environ.items() if not kk.startswith("SGMSE_")}, LOAD_SECONDS=str(seconds)),
-                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                            env=dict({kk: vv for kk, vv in os.environ.items() if not kk.startswith("SGMSE_")}, LOAD_SECONDS=str(max(seconds, 600)),
+                                     LOAD_STOP_FILE=stop_file),
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     try:
-        time.sleep(12)                       # (library load and first forward of the load process)
-        assert load.poll() is None, "the load process ended before the checks began"
+        t0 = time.time()
+        line = ""
+        while "LOAD-RUNNING" not in line:
+            line = load.stdout.readline()
+            assert line or load.poll() is None, "the load process ended before it started loading the device"
+            assert time.time() - t0 < 400, "the load process did not come up"
         for k, (f, reps) in cases.items():
             bad = sum(0 if torch.equal(f().cpu(), ref[k]) else 1 for _ in range(reps))
             print(f"under outside load: {k}: {reps - bad} of {reps} identical to the solo result")
             assert bad == 0, (k, bad, reps)
-        assert load.poll() is None, "the load process ended before the checks did: lengthen `seconds`"
+        assert load.poll() is None, "the load process ended before the checks did"
     finally:
-        load.wait(timeout=300)
+        open(stop_file, "w").close()                 # the load loop ends by itself within one forward ...
+        try:
+            load.wait(timeout=60)
+        except subprocess.TimeoutExpired:            # ... or is ended
+            load.kill()
+            load.wait(timeout=60)
 
 
 def check_ragged_batch(dev, name="fwd_nf32", frames=(128, 64, 192), sampler=True, quick=False):

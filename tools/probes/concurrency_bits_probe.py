@@ -27,8 +27,11 @@ if "--load" in sys.argv:
     g = torch.Generator().manual_seed(5)
     x = (torch.randn(4, 2, 256, 128, dtype=torch.complex64, generator=g) * 0.3).cuda()
     t = torch.full((4,), 0.5).cuda()
+    net(x, t); torch.cuda.synchronize()
+    print("LOAD-RUNNING", flush=True)              # (tests wait for this line: the device is loaded from here on)
     t0 = time.time()
-    while time.time() - t0 < float(os.environ.get("LOAD_SECONDS", "60")):
+    stop = os.environ.get("LOAD_STOP_FILE")        # (ended cleanly by whoever started it: the file appears)
+    while time.time() - t0 < float(os.environ.get("LOAD_SECONDS", "60")) and not (stop and os.path.exists(stop)):
         net(x, t)
     torch.cuda.synchronize()
     sys.exit(0)
