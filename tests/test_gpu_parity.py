@@ -557,6 +557,13 @@ def test_side_stream_never_changes_a_bit(hip, name):
         P.check_xcd_map_bitwise(hip, name, knob="SGMSE_SIDE_STREAM")
 
 
+@pytest.mark.parametrize("name", ["fwd_nf32", "fwd_nf128"])
+def test_results_do_not_depend_on_what_the_lds_held(hip, name):
+    """SGMSE_POISON_LDS=1 (round 6): NaN bit patterns in the whole LDS of every CU in front of every launch of the eager forward -- a kernel that
+    reads LDS it never wrote (its result would then depend on the previous workgroup on that CU, i.e. on what else runs on the device) changes bits."""
+    P.check_xcd_map_bitwise(hip, name, knob="SGMSE_POISON_LDS")
+
+
 def test_results_do_not_depend_on_what_else_runs_on_the_device(hip):
     """Round 6: a second process loads the GPU while this one repeats the C -> 4 pyramid convolution, the networks and a seeded sampler run:
     every result must equal its solo result bit for bit (conv3x3_thin_kernel's packed FMAs did not: kernels_conv_thin.h)."""
