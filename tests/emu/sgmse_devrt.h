@@ -28,7 +28,6 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 typedef float f32x16 __attribute__((vector_size(64)));
 typedef float f32x4 __attribute__((vector_size(16)));
 typedef float f32x2 __attribute__((vector_size(8)));
-static inline f32x2 drt_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
 typedef uint32_t u32x4 __attribute__((vector_size(16)));
 
 #define __global__
