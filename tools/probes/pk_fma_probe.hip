@@ -14,7 +14,8 @@ __global__ __launch_bounds__(256, 3) void k(const float* in, const float* w, flo
   __shared__ alignas(16) float s_w[2][144];
   const int tid = threadIdx.x, row = tid >> 4, cx = (tid & 15) * 4;
   f2 acc[2][4];
-  for (int a = 0; a < 2; ++a) for (int p = 0; p < 4; ++p) acc[a][p] = f2{0.f, 0.f};
+  double dacc[2][4];
+  for (int a = 0; a < 2; ++a) for (int p = 0; p < 4; ++p) { acc[a][p] = f2{0.f, 0.f}; dacc[a][p] = 0.0; }
   const float* src = in + (size_t)blockIdx.x * 4 * 18 * 68;
   for (int st = 0; st < nst; ++st) {
     for (int i = tid; i < 4 * 18 * 68; i += 256) s_in[st & 1][i] = src[i] * (1.f + 0.001f * st);
@@ -33,7 +34,9 @@ __global__ __launch_bounds__(256, 3) void k(const float* in, const float* w, flo
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const f2 v = {iv[p + dx], iv[p + dx]};
-          if (PK) { acc[0][p] = __builtin_elementwise_fma(w01, v, acc[0][p]); acc[1][p] = __builtin_elementwise_fma(w23, v, acc[1][p]); }
+          if (PK == 1) { acc[0][p] = __builtin_elementwise_fma(w01, v, acc[0][p]); acc[1][p] = __builtin_elementwise_fma(w23, v, acc[1][p]); }
+          else if (PK == 2) { acc[0][p] = acc[0][p] + w01 * v; acc[1][p] = acc[1][p] + w23 * v; }        // (-ffp-contract=off: v_pk_mul_f32 + v_pk_add_f32)
+          else if (PK == 3) { dacc[0][p] = fma((double)w01[0], (double)v[0], dacc[0][p]); dacc[1][p] = fma((double)w23[0], (double)v[0], dacc[1][p]); }
           else { acc[0][p] = f2{fmaf(w01[0], v[0], acc[0][p][0]), fmaf(w01[1], v[1], acc[0][p][1])};
                  acc[1][p] = f2{fmaf(w23[0], v[0], acc[1][p][0]), fmaf(w23[1], v[1], acc[1][p][1])}; }
         }
@@ -42,7 +45,10 @@ __global__ __launch_bounds__(256, 3) void k(const float* in, const float* w, flo
     __syncthreads();
   }
   float* o = out + ((size_t)blockIdx.x * 256 + tid) * 16;
-  for (int a = 0; a < 2; ++a) for (int p = 0; p < 4; ++p) { o[(a * 4 + p) * 2] = acc[a][p][0]; o[(a * 4 + p) * 2 + 1] = acc[a][p][1]; }
+  for (int a = 0; a < 2; ++a) for (int p = 0; p < 4; ++p) {
+    if (PK == 3) { o[(a * 4 + p) * 2] = (float)dacc[a][p]; o[(a * 4 + p) * 2 + 1] = (float)(dacc[a][p] * 0.5); }
+    else { o[(a * 4 + p) * 2] = acc[a][p][0]; o[(a * 4 + p) * 2 + 1] = acc[a][p][1]; }
+  }
 }
 // load for the second process: waves that keep the MATRIX pipe of every SIMD busy (what the network's kernels do)
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -64,19 +70,24 @@ int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "load")) { for (int i = 0; i < 4000; ++i) k<0><<<nb, 256>>>(din, dw, dout, nst); hipDeviceSynchronize(); return 0; }
   if (argc > 1 && !strcmp(argv[1], "mfmaload")) { for (int i = 0; i < 600; ++i) mfma_spin<<<2048, 256>>>(dout, 20000); hipDeviceSynchronize(); return 0; }
   std::vector<float> ref(nout), got(nout);
-  for (int pk = 0; pk < 2; ++pk) {
-    if (pk) k<1><<<nb, 256>>>(din, dw, dout, nst); else k<0><<<nb, 256>>>(din, dw, dout, nst);
+  const char* names[4] = {"2 x v_fma_f32 (scalar; needs -fno-slp-vectorize)", "v_pk_fma_f32", "v_pk_mul_f32 + v_pk_add_f32 (-ffp-contract=off)", "v_fma_f64"};
+  for (int pk = 0; pk < 4; ++pk) {
+    auto launch = [&]() {
+      if (pk == 0) k<0><<<nb, 256>>>(din, dw, dout, nst); else if (pk == 1) k<1><<<nb, 256>>>(din, dw, dout, nst);
+      else if (pk == 2) k<2><<<nb, 256>>>(din, dw, dout, nst); else k<3><<<nb, 256>>>(din, dw, dout, nst);
+    };
+    launch();
     hipMemcpy(ref.data(), dout, nout * 4, hipMemcpyDeviceToHost);
     int badruns = 0; long lanes[4] = {0, 0, 0, 0}, elem[2] = {0, 0};
-    for (int it = 0; it < 60; ++it) {
-      if (pk) k<1><<<nb, 256>>>(din, dw, dout, nst); else k<0><<<nb, 256>>>(din, dw, dout, nst);
+    for (int it = 0; it < 40; ++it) {
+      launch();
       hipMemcpy(got.data(), dout, nout * 4, hipMemcpyDeviceToHost);
       bool bad = false;
       for (size_t i = 0; i < nout; ++i) if (memcmp(&got[i], &ref[i], 4)) { bad = true; ++lanes[((i / 16) & 63) >> 4]; ++elem[i & 1]; }
       badruns += bad;
     }
-    printf("%s: %d of 60 launches differ from the first; differing values by lane quarter [0-15 16-31 32-47 48-63] = [%ld %ld %ld %ld], by pair element [low high] = [%ld %ld]\n",
-           pk ? "v_pk_fma_f32" : "2 x v_fma_f32 ", badruns, lanes[0], lanes[1], lanes[2], lanes[3], elem[0], elem[1]);
+    printf("%-52s %2d of 40 launches differ from the first; by lane quarter [0-15 16-31 32-47 48-63] = [%ld %ld %ld %ld], by pair element [low high] = [%ld %ld]\n",
+           names[pk], badruns, lanes[0], lanes[1], lanes[2], lanes[3], elem[0], elem[1]);
   }
   return 0;
 }
