@@ -34,6 +34,11 @@ conv_case("conv3x3 wino 128->128 @256x64", 1, 128, 128, 256, 64, force_split="wi
 conv_case("conv3x3 wino4 128->128 @128x32", 1, 128, 128, 128, 32, force_split="wino4")
 conv_case("conv3x3 fp16x2 256->256 @32x8", 1, 256, 256, 32, 8, force_split="fp16x2")
 conv_case("conv3x3 thin 128->4 @256x64", 1, 128, 4, 256, 64, force_split="thin")
+if "--more" in sys.argv or "--as-load" in sys.argv:          # further candidates for the aggressor side (find_aggressor.sh MORE=1)
+    conv_case("conv3x3 bf16x3 256->256 @32x8", 1, 256, 256, 32, 8, force_split="bf16x3")
+    conv_case("conv3x3 fp16x2 128->4 @64x16 (thin split shape)", 1, 128, 4, 64, 16, force_split="fp16x2")
+    conv_case("conv1x1 fp16x2 256->128 @64x16", 1, 256, 128, 64, 16, ks=1, xform=False, force_split="fp16x2")
+    conv_case("conv3x3 fp16x2 128->128 @256x64", 1, 128, 128, 256, 64, force_split="fp16x2")
 conv_case("conv1x1 fp32 256->128 @64x16", 1, 256, 128, 64, 16, ks=1, xform=False)
 conv_case("conv1x1 direct 4->128 @128x32", 1, 4, 128, 128, 32, ks=1, xform=False, force_direct=True)
 xg, wg, bg = R(1, 128, 128, 32), R(128), R(128)
