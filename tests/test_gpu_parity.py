@@ -530,6 +530,18 @@ def test_adaptive_ode_sampler_matches_the_reference_run(hip, name):
     P.check_ode_rk45(hip, name=name)
 
 
+def test_calibration_streams_of_the_counter_passes(hip):
+    """sgmse_calib_stream (measurement entry of the C ABI, round 6): known-size read / write streams at 8 and 16 bytes per lane; bad arguments refused."""
+    from sgmse_amd import _lib
+    ctx = _lib.Context(hip)
+    for mode in (0, 1):
+        for width in (8, 16):
+            ms = ctx.calib_stream(mode, width, 64 << 20)
+            assert 0.0 < ms < 50.0, (mode, width, ms)
+    with pytest.raises(Exception):
+        ctx.calib_stream(0, 12, 1 << 20)
+
+
 def test_profile_of_one_evaluation_times_the_ordinary_forward(hip):
     P.check_profile_forward(hip, "fwd_nf32")
 
