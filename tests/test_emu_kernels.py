@@ -160,6 +160,21 @@ def test_fir(emu):
     P.check_fir_golden(emu)
 
 
+def test_upfirdn2d_refuses_what_the_reference_op_refuses(emu):
+    """op/upfirdn2d_kernel.cu:311 dispatches float / double / half only, upfirdn2d.cpp:15-16 checks both tensors' device: other element types
+    raise instead of running silently as float32."""
+    import torch
+    from sgmse_amd import ops
+    x, k = torch.randn(1, 2, 8, 8), torch.ones(4, 4) / 16
+    assert ops.upfirdn2d(x, k, down=2, pad=(1, 1)).dtype == torch.float32
+    assert ops.upfirdn2d(x.double(), k, down=2, pad=(1, 1)).dtype == torch.float64        # (the kernel's dtype is cast to the input's)
+    for bad in (x.to(torch.bfloat16), x.to(torch.int32)):
+        with pytest.raises(ValueError):
+            ops.upfirdn2d(bad, k, down=2, pad=(1, 1))
+    with pytest.raises(ValueError):
+        ops.upfirdn2d(x, k.to(torch.int64), down=2, pad=(1, 1))
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 40), (1, 32, 4), (1, 256, 100), (1, 64, 160)])
 def test_attention(emu, shape):
     P.check_attention(emu, *shape)
