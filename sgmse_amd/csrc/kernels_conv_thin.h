@@ -13,9 +13,9 @@
 //   workgroup = 256 threads = 16 rows x 64 columns of one utterance (thread: row t / 16, columns 4 (t % 16) .. + 3), 3 per CU;
 //   the FMAs of an output-channel pair sit side by side (weight pair x the input value).  ROUND 6: as TWO v_fma_f32, no longer one
 //   v_pk_fma_f32 -- the packed instruction's low element came out wrong in lanes 48-63 whenever another process (or another queue of this
-//   one) ran on the GPU at the same time, see the note in fmas() below; measured at batch 32: 0.690 / 0.211 ms per launch against
-//   0.693 / 0.204 with the packed form (the kernel is bound by its LDS reads, not by FMA issue; round 4's 3-4 % for scalar FMAs was
-//   another form of the kernel);
+//   one) ran on the GPU at the same time, see the note in fmas() below; same-box A B B A at batch 32: 0.726 / 0.719 ms (256 x 512) and
+//   0.218 / 0.222 ms (128 x 256) per launch against 0.676 / 0.688 and 0.193 / 0.196 with the packed form: +6 % / +13 % on these two launches,
+//   0.065 ms of a 94 ms evaluation -- the price of results that do not depend on the device's other tenants;
 //   K-stages of 4 input channels: the tile with halo (18 x 66, row stride 68 floats so that a thread's 16-byte read is aligned) after the
 //   fused producer (GroupNorm affine + SiLU, zero padding applied behind it), double-buffered in LDS (2 x 19.6 KB: three workgroups per
 //   CU); the raw values of stage s + 1 are loaded (coalesced dwords, 20 per thread) before the FMAs of stage s and pass the producer behind them;
